@@ -1,0 +1,1217 @@
+// scorer.hip -- MI355X (gfx950) implementation of include/gfalign_scorer.h.
+//
+// What it computes: reference src/eval.cpp:67-108 (evaluatePath) for a batch
+// of candidate paths against one shard of GAF alignments; the per-pair
+// decision follows src/alignments.cpp:499-554 exactly (DESIGN.md "Exact
+// decision rule").  How it computes it is unrelated to the reference:
+//
+//   create      alignments -> dense local node ids, bucketed by length,
+//               sorted by content, stored as 64-alignment "items" in
+//               step-major order (one coalesced 128-B load per step per wave).
+//   k_prep      one wave per candidate path: builds the path's lookup image
+//               (first-occurrence table by node, occurrence chain, steps) in
+//               LDS and writes it to HBM; also the `unaligned` counter.
+//   k_scan      workgroup = T path images staged in LDS x one chunk of items;
+//               one lane per alignment, its steps in registers, reused across
+//               the T paths; ballot/popcount per (wave, path); one atomic per
+//               counter per workgroup.  Pairs the cheap rules cannot decide
+//               go to a worklist.
+//   k_dp        exact Needleman-Wunsch + traceback-exit propagation for the
+//               worklist (rare "start-overhang" pairs).
+//   k_pairs     the same exact DP for every alignment of one path, both
+//               orientations (evalPath's per-alignment scores).
+//
+// No MFMA anywhere: the work is integer compares and LDS table lookups.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "gfalign_scorer.h"
+
+namespace {
+
+constexpr int WAVE = 64;
+constexpr int SCAN_THREADS = 512;
+constexpr int SCAN_WAVES = SCAN_THREADS / WAVE;
+constexpr int MAX_REG_M = 16;          // alignments up to this length live in VGPRs
+constexpr int MAX_TILE = 64;           // lane p of a wave owns path p's counter
+constexpr int LDS_BUDGET = 80 * 1024;  // two workgroups per CU (160 KiB LDS)
+constexpr int DP_THREADS = 64;
+constexpr int DP_BLOCKS = 512;
+
+constexpr uint32_t ENT_NONE = 0xFFFFu;     // table / chain: no occurrence
+constexpr uint32_t ENT_POS = 0x03FFu;      // position in the path (0..999)
+constexpr uint32_t ENT_NOMATCH = 0x4000u;  // step there equals nothing
+constexpr uint32_t ENT_NEG = 0x8000u;      // step there is '-'
+constexpr uint32_t STEP_NOMATCH = 0xFFFEu; // path step that equals nothing
+constexpr uint32_t STEP_INVALID = 0xFFFFu; // padding lane of an item
+constexpr int MAX_LOCAL_NODES = 32766;     // 2*V-1 must stay below STEP_NOMATCH
+
+constexpr uint32_t ST_BAD_LEN = 1u, ST_BAD_ID = 2u, ST_DP_OVERFLOW = 4u;
+
+thread_local char g_err[512] = "";
+
+void set_err(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+#define HIP_TRY(expr)                                                          \
+    do {                                                                       \
+        hipError_t e_ = (expr);                                                \
+        if (e_ != hipSuccess) {                                                \
+            set_err("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),     \
+                    __FILE__, __LINE__);                                       \
+            return GFAL_E_HIP;                                                 \
+        }                                                                      \
+    } while (0)
+
+// Geometry of one path image, in uint16 units.  Shared by host and device.
+struct ImageLayout {
+    int v2;        // first-occurrence table entries (n_local rounded up to even)
+    int nm;        // capacity of the chain / step arrays (even)
+    int total;     // whole image, multiple of 8 (16 bytes)
+    __host__ __device__ int first_at() const { return 0; }
+    __host__ __device__ int next_at() const { return v2; }
+    __host__ __device__ int step_at() const { return v2 + nm; }
+    __host__ __device__ int len_at() const { return v2 + 2 * nm; }
+};
+
+ImageLayout make_layout(int n_local, int max_len)
+{
+    ImageLayout L;
+    L.v2 = (n_local + 1) & ~1;
+    L.nm = (max_len + 1) & ~1;
+    L.total = (L.v2 + 2 * L.nm + 2 + 7) & ~7;
+    return L;
+}
+
+// Items: 64 alignments of equal length m, step-major.  Step t of lane l of
+// item k sits at steps[item_base[k] * 64 + t * 64 + l].
+struct Items {
+    const uint16_t *steps;
+    const uint32_t *base;   // per item, in units of 64 uint16
+    const uint16_t *len;    // per item, m
+    int n_items;
+};
+
+// --------------------------------------------------------------------------
+// k_prep: candidate path -> lookup image (+ counter initialisation)
+// --------------------------------------------------------------------------
+__global__ __launch_bounds__(WAVE) void k_prep(
+    const int32_t *__restrict__ path_off, const int32_t *__restrict__ path_steps,
+    int n_paths, int64_t total_steps, int max_len,
+    const int32_t *__restrict__ node_local, int n_nodes,
+    const uint32_t *__restrict__ node_hist, uint32_t hist_total,
+    uint32_t n_empty, int filter, ImageLayout L,
+    uint16_t *__restrict__ images, uint32_t *__restrict__ counts,
+    uint32_t *__restrict__ status)
+{
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+    uint16_t *img = smem;
+    uint16_t *lids = smem + L.total;   // nm entries: local node id per step
+    const int p = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (p >= n_paths) return;
+
+    int64_t off = path_off[p];
+    int64_t end = path_off[p + 1];
+    int n = (int)(end - off);
+    bool len_ok = off >= 0 && end <= total_steps && end >= off && n >= 1 &&
+                  n <= max_len && n <= GFAL_MAX_STEPS;
+    if (!len_ok) {
+        if (lane == 0) atomicOr(status, ST_BAD_LEN);
+        n = 0;
+    }
+
+    uint16_t *first = img + L.first_at();
+    uint16_t *next = img + L.next_at();
+    uint16_t *step = img + L.step_at();
+    for (int i = lane; i < L.total; i += WAVE) img[i] = (uint16_t)ENT_NONE;
+    __syncthreads();
+
+    bool id_ok = true;
+    for (int i = lane; i < n; i += WAVE) {
+        int32_t s = path_steps[off + i];
+        bool other = (s & GFAL_STEP_OTHER) != 0;
+        int32_t id = (s & ~GFAL_STEP_OTHER) >> 1;
+        uint32_t neg = (uint32_t)s & 1u;
+        int32_t lid = -1;
+        if (s < 0 || id >= n_nodes) id_ok = false;
+        else lid = node_local[id];
+        step[i] = (uint16_t)((lid < 0 || other) ? STEP_NOMATCH
+                                                 : (((uint32_t)lid << 1) | neg));
+        lids[i] = (uint16_t)(lid < 0 ? ENT_NONE : (uint32_t)lid);
+    }
+    if (!id_ok) atomicOr(status, ST_BAD_ID);
+    __syncthreads();
+
+    // Occurrence chains in increasing position order: walk the path backwards.
+    if (lane == 0) {
+        for (int i = n - 1; i >= 0; --i) {
+            uint32_t lid = lids[i];
+            if (lid == ENT_NONE) continue;
+            uint32_t code = step[i];
+            uint32_t ent = (uint32_t)i;
+            if (code == STEP_NOMATCH) ent |= ENT_NOMATCH;
+            else if (code & 1u) ent |= ENT_NEG;
+            next[i] = first[lid];
+            first[lid] = (uint16_t)ent;
+        }
+        img[L.len_at()] = (uint16_t)n;
+        img[L.len_at() + 1] = 0;
+    }
+    __syncthreads();
+
+    // unaligned (src/eval.cpp:83-88) = steps of all alignments whose node is
+    // not on the path = total - sum over the distinct path nodes of how many
+    // alignment steps carry them.  A node's last occurrence (chain tail)
+    // stands for it.
+    uint32_t covered = 0;
+    if (filter) {
+        for (int i = lane; i < n; i += WAVE) {
+            uint32_t lid = lids[i];
+            if (lid != ENT_NONE && next[i] == ENT_NONE) covered += node_hist[lid];
+        }
+    }
+
+    uint16_t *dst = images + (size_t)p * L.total;
+    for (int i = lane * 2; i < L.total; i += WAVE * 2)
+        *reinterpret_cast<uint32_t *>(dst + i) =
+            *reinterpret_cast<const uint32_t *>(img + i);
+
+    for (int o = 32; o > 0; o >>= 1) covered += __shfl_down(covered, o, WAVE);
+    if (lane == 0) {
+        counts[p] = 0;
+        counts[n_paths + p] = n_empty;
+        counts[2 * n_paths + p] = filter ? hist_total - covered : 0u;
+    }
+}
+
+// --------------------------------------------------------------------------
+// k_scan
+// --------------------------------------------------------------------------
+struct ScanArgs {
+    Items items;
+    const uint16_t *images;   // n_paths images
+    ImageLayout L;
+    int n_paths;
+    int tile;                 // paths per workgroup (<= MAX_TILE)
+    int n_tiles;
+    int n_chunks;             // multiple of 8
+    int items_per_chunk;
+    int filter;
+    uint32_t *counts;         // bad[P] | good[P] | unaligned[P]
+    unsigned long long *worklist;
+    uint32_t *wl_count;
+    uint32_t wl_capacity;
+    uint32_t *status;
+};
+
+struct PathView {
+    const uint16_t *first, *next, *step;
+    int n;
+    uint32_t a0;
+};
+
+__device__ __forceinline__ uint32_t lanes_below(unsigned long long m, int lane)
+{
+    return __popcll(m & ((1ull << lane) - 1ull));
+}
+
+// Append the lanes in `want` to the worklist.
+__device__ __forceinline__ void push_pairs(const ScanArgs &a, bool want, int lane,
+                                           uint32_t path_global, uint32_t slot)
+{
+    unsigned long long m = __ballot(want);
+    if (m == 0) return;
+    uint32_t base = 0;
+    int leader = __ffsll((long long)m) - 1;
+    if (lane == leader) base = atomicAdd(a.wl_count, (uint32_t)__popcll(m));
+    base = __shfl(base, leader, WAVE);
+    if (want) {
+        uint32_t idx = base + lanes_below(m, lane);
+        if (idx < a.wl_capacity)
+            a.worklist[idx] = ((unsigned long long)path_global << 32) | slot;
+        else
+            atomicOr(a.status, ST_DP_OVERFLOW);
+    }
+}
+
+// One item (64 alignments of length M, steps in b[]) against one staged path.
+// Returns through good/bad whether this lane's alignment was decided here.
+template <int M>
+__device__ __forceinline__ void eval_item(const ScanArgs &a, const PathView &pv,
+                                          const uint32_t (&b)[M], bool valid,
+                                          int lane, uint32_t path_global,
+                                          uint32_t slot, bool &good, bool &bad)
+{
+    good = false;
+    bad = false;
+    const uint32_t b0 = b[0];
+    uint32_t e0 = valid ? (uint32_t)pv.first[b0 >> 1] : ENT_NONE;
+    // search mode: an alignment whose first node is off the path is filtered
+    // (src/eval.cpp:83-90); if that holds for the whole wave, nothing to do.
+    if (a.filter && !__any(e0 != ENT_NONE)) return;
+
+    bool found = false;
+    uint32_t e = e0;
+    while (__any(e != ENT_NONE)) {
+        if (e != ENT_NONE) {
+            int pos = (int)(e & ENT_POS);
+            // dir 0: the path step equals b0 -> B may start here going right.
+            // dir 1: it is b0's complement  -> rc(B) may END here (going left).
+            uint32_t dir = (e >> 15) ^ (b0 & 1u);
+            bool fits = !(e & ENT_NOMATCH) &&
+                        (dir ? (pos >= M - 1) : (pos + M <= pv.n));
+            // a lane whose window does not fit re-reads step[0] (in range)
+            int at = fits ? pos : 0;
+            int sgn = fits ? (dir ? -1 : 1) : 0;
+            bool ok = fits;
+#pragma unroll
+            for (int t = 1; t < M; ++t)
+                ok &= (uint32_t)pv.step[at + sgn * t] == (b[t] ^ dir);
+            found |= ok;
+            e = found ? ENT_NONE : (uint32_t)pv.next[pos];
+        }
+    }
+    good = found;
+    bool open = valid && !found;
+    if (!__any(open)) return;
+
+    if (a.filter) {
+        bool present = e0 != ENT_NONE;
+#pragma unroll
+        for (int t = 1; t < M; ++t)
+            present &= (!open) || pv.first[b[t] >> 1] != ENT_NONE;
+        open &= present;
+    }
+    if (M > pv.n) {                       // src/alignments.cpp:500 row-0 bound
+        good |= open;
+        return;
+    }
+    // Only a suffix of B (or of rc(B)) equal to a prefix of the path can still
+    // make the traceback free; that needs the path's first step inside B.
+    bool cand = false;
+#pragma unroll
+    for (int t = 1; t < M; ++t) cand |= b[t] == pv.a0;
+#pragma unroll
+    for (int t = 0; t < M - 1; ++t) cand |= (b[t] ^ 1u) == pv.a0;
+    cand &= open;
+    bad = open && !cand;
+    push_pairs(a, cand, lane, path_global, slot);
+}
+
+// Same decision for alignments too long for registers: steps re-read from the
+// item (L1/L2 hot, coalesced).
+__device__ __noinline__ void eval_item_long(const ScanArgs &a, const PathView &pv,
+                                            const uint16_t *__restrict__ bp, int M,
+                                            bool valid, int lane,
+                                            uint32_t path_global, uint32_t slot,
+                                            bool &good, bool &bad)
+{
+    good = false;
+    bad = false;
+    const uint32_t b0 = valid ? (uint32_t)bp[0] : 0u;
+    uint32_t e0 = valid ? (uint32_t)pv.first[b0 >> 1] : ENT_NONE;
+    if (a.filter && !__any(e0 != ENT_NONE)) return;
+
+    bool found = false;
+    uint32_t e = e0;
+    while (__any(e != ENT_NONE)) {
+        if (e != ENT_NONE) {
+            int pos = (int)(e & ENT_POS);
+            uint32_t dir = (e >> 15) ^ (b0 & 1u);
+            bool fits = !(e & ENT_NOMATCH) &&
+                        (dir ? (pos >= M - 1) : (pos + M <= pv.n));
+            int sgn = dir ? -1 : 1;
+            bool ok = fits;
+            for (int t = 1; ok && t < M; ++t)
+                ok = (uint32_t)pv.step[pos + sgn * t] == ((uint32_t)bp[t * WAVE] ^ dir);
+            found |= ok;
+            e = found ? ENT_NONE : (uint32_t)pv.next[pos];
+        }
+    }
+    good = found;
+    bool open = valid && !found;
+    if (!__any(open)) return;
+
+    if (a.filter && open) {
+        bool present = e0 != ENT_NONE;
+        for (int t = 1; present && t < M; ++t)
+            present = pv.first[(uint32_t)bp[t * WAVE] >> 1] != ENT_NONE;
+        open = present;
+    }
+    if (M > pv.n) {
+        good |= open;
+        return;
+    }
+    bool cand = false;
+    if (open) {
+        for (int t = 0; t < M; ++t) {
+            uint32_t bt = bp[t * WAVE];
+            cand |= (t >= 1 && bt == pv.a0) || (t < M - 1 && (bt ^ 1u) == pv.a0);
+        }
+    }
+    bad = open && !cand;
+    push_pairs(a, cand, lane, path_global, slot);
+}
+
+template <int M>
+__device__ __forceinline__ void scan_item(const ScanArgs &a, const uint16_t *lds,
+                                          int tile_paths, int path0,
+                                          const uint16_t *__restrict__ bp, int lane,
+                                          uint32_t slot, uint32_t &cnt_good,
+                                          uint32_t &cnt_bad)
+{
+    uint32_t b[M];
+#pragma unroll
+    for (int t = 0; t < M; ++t) b[t] = bp[t * WAVE];
+    const bool valid = b[0] != STEP_INVALID;
+    if (!valid) {           // keep table indices in range on padding lanes
+#pragma unroll
+        for (int t = 0; t < M; ++t) b[t] = 0;
+    }
+    for (int p = 0; p < tile_paths; ++p) {
+        const uint16_t *img = lds + p * a.L.total;
+        PathView pv;
+        pv.first = img + a.L.first_at();
+        pv.next = img + a.L.next_at();
+        pv.step = img + a.L.step_at();
+        pv.n = __builtin_amdgcn_readfirstlane((int)img[a.L.len_at()]);
+        pv.a0 = __builtin_amdgcn_readfirstlane((uint32_t)pv.step[0]);
+        bool good, bad;
+        eval_item<M>(a, pv, b, valid, lane, (uint32_t)(path0 + p), slot, good, bad);
+        uint32_t g = (uint32_t)__popcll(__ballot(good));
+        uint32_t d = (uint32_t)__popcll(__ballot(bad));
+        if (lane == p) {
+            cnt_good += g;
+            cnt_bad += d;
+        }
+    }
+}
+
+__global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan(ScanArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & (WAVE - 1);
+    const int wave = tid >> 6;
+
+    // Workgroups b and b+8 share an XCD (observed round-robin dispatch): keep
+    // every tile of one alignment chunk on one XCD so the chunk stays in that
+    // XCD's L2.  Speed only -- any placement gives the same counters.
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7;
+    const int within = bid >> 3;
+    const int tile_id = within % a.n_tiles;
+    const int chunk = (within / a.n_tiles) * 8 + xcd;
+
+    const int path0 = tile_id * a.tile;
+    const int tile_paths = min(a.tile, a.n_paths - path0);
+
+    // stage the tile's images: contiguous in HBM, 16 bytes per lane
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(
+            a.images + (size_t)path0 * a.L.total);
+        uint4 *dst = reinterpret_cast<uint4 *>(lds);
+        const int n16 = tile_paths * a.L.total / 8;
+        for (int i = tid; i < n16; i += SCAN_THREADS) dst[i] = src[i];
+    }
+    __syncthreads();
+
+    uint32_t cnt_good = 0, cnt_bad = 0;   // lane p: path0 + p
+    const int item_begin = chunk * a.items_per_chunk;
+    const int item_end = min(item_begin + a.items_per_chunk, a.items.n_items);
+    for (int it = item_begin + wave; it < item_end; it += SCAN_WAVES) {
+        const int M = __builtin_amdgcn_readfirstlane((int)a.items.len[it]);
+        const uint16_t *bp =
+            a.items.steps + (size_t)a.items.base[it] * WAVE + lane;
+        const uint32_t slot = (uint32_t)it * WAVE + lane;
+        switch (M) {
+#define GFAL_CASE(MM)                                                          \
+    case MM:                                                                   \
+        scan_item<MM>(a, lds, tile_paths, path0, bp, lane, slot, cnt_good,     \
+                      cnt_bad);                                                \
+        break;
+            GFAL_CASE(1) GFAL_CASE(2) GFAL_CASE(3) GFAL_CASE(4)
+            GFAL_CASE(5) GFAL_CASE(6) GFAL_CASE(7) GFAL_CASE(8)
+            GFAL_CASE(9) GFAL_CASE(10) GFAL_CASE(11) GFAL_CASE(12)
+            GFAL_CASE(13) GFAL_CASE(14) GFAL_CASE(15) GFAL_CASE(16)
+#undef GFAL_CASE
+        default: {
+            const bool valid = bp[0] != STEP_INVALID;
+            for (int p = 0; p < tile_paths; ++p) {
+                const uint16_t *img = lds + p * a.L.total;
+                PathView pv;
+                pv.first = img + a.L.first_at();
+                pv.next = img + a.L.next_at();
+                pv.step = img + a.L.step_at();
+                pv.n = __builtin_amdgcn_readfirstlane((int)img[a.L.len_at()]);
+                pv.a0 = __builtin_amdgcn_readfirstlane((uint32_t)pv.step[0]);
+                bool good, bad;
+                eval_item_long(a, pv, bp, M, valid, lane, (uint32_t)(path0 + p),
+                               slot, good, bad);
+                uint32_t g = (uint32_t)__popcll(__ballot(good));
+                uint32_t d = (uint32_t)__popcll(__ballot(bad));
+                if (lane == p) {
+                    cnt_good += g;
+                    cnt_bad += d;
+                }
+            }
+        }
+        }
+    }
+
+    // workgroup reduction through LDS (images are dead now), then one atomic
+    // per counter per workgroup
+    __syncthreads();
+    uint32_t *red = reinterpret_cast<uint32_t *>(lds);
+    if (tid < 2 * MAX_TILE) red[tid] = 0;
+    __syncthreads();
+    if (lane < tile_paths) {
+        if (cnt_bad) atomicAdd(&red[lane], cnt_bad);
+        if (cnt_good) atomicAdd(&red[MAX_TILE + lane], cnt_good);
+    }
+    __syncthreads();
+    if (tid < tile_paths) {
+        uint32_t d = red[tid], g = red[MAX_TILE + tid];
+        if (d) atomicAdd(&a.counts[path0 + tid], d);
+        if (g) atomicAdd(&a.counts[a.n_paths + path0 + tid], g);
+    }
+}
+
+// --------------------------------------------------------------------------
+// Exact decision: Needleman-Wunsch fill (src/alignments.cpp:499-509) with the
+// traceback (src/alignments.cpp:511-554) folded into the forward pass.
+//
+// The traceback's direction at a cell depends only on the table, and its cost
+// equals the table's own move cost everywhere except on row 0 / column 0,
+// which it walks for free.  Hence  score = dp[n][m] - dp[exit]  where `exit`
+// is the first row-0/column-0 cell the traceback reaches.  exit-values are
+// propagated forward with the table, one row at a time:  X[i][j] =
+// X[predecessor chosen by the traceback at (i,j)].
+//
+// Row state lives in `row` (one packed {dp,X} int16 pair per column), strided
+// so that neighbouring threads touch neighbouring words.
+// --------------------------------------------------------------------------
+struct StepsA {   // candidate path steps inside an image (HBM)
+    const uint16_t *step;
+    int n;
+};
+struct StepsB {   // one alignment inside an item
+    const uint16_t *p;   // step 0 of this lane
+    int m;
+    uint32_t flip;       // 0: as stored, 1: reverse complement
+    __device__ __forceinline__ uint32_t at(int j) const
+    {
+        return flip ? ((uint32_t)p[(m - 1 - j) * WAVE] ^ 1u) : (uint32_t)p[j * WAVE];
+    }
+};
+
+__device__ __forceinline__ uint32_t pack_cell(int dp, int x)
+{
+    return ((uint32_t)dp & 0xFFFFu) | ((uint32_t)x << 16);
+}
+__device__ __forceinline__ int cell_dp(uint32_t c) { return (int)(int16_t)(c & 0xFFFFu); }
+__device__ __forceinline__ int cell_x(uint32_t c) { return (int)(int16_t)(c >> 16); }
+
+__device__ int traceback_score(const StepsA &A, const StepsB &B, uint32_t *row,
+                               int stride)
+{
+    const int n = A.n, m = B.m;
+    for (int j = 0; j <= m; ++j) {
+        int v = (j <= n) ? -j : 0;           // :500, row 0 reaches column n only
+        row[(size_t)j * stride] = pack_cell(v, v);
+    }
+    for (int i = 1; i <= n; ++i) {
+        const uint32_t ai = A.step[i - 1];
+        uint32_t c = row[0];
+        int diag_dp = cell_dp(c), diag_x = cell_x(c);
+        row[0] = pack_cell(0, 0);            // column 0 is never written: 0
+        int left_dp = 0, left_x = 0;
+        for (int j = 1; j <= m; ++j) {
+            c = row[(size_t)j * stride];
+            const int up_dp = cell_dp(c), up_x = cell_x(c);
+            const int sub = (ai == B.at(j - 1)) ? 0 : -1;
+            const int d = diag_dp + sub;
+            const int u = up_dp + (j < m ? -1 : 0);   // :504 free in last column
+            const int l = left_dp - 1;
+            const int v = max(d, max(u, l));
+            int x;
+            if (v == d) x = diag_x;                    // :527
+            else if (up_dp >= left_dp) x = up_x;       // :534
+            else x = left_x;                           // :541
+            row[(size_t)j * stride] = pack_cell(v, x);
+            diag_dp = up_dp;
+            diag_x = up_x;
+            left_dp = v;
+            left_x = x;
+        }
+    }
+    uint32_t c = row[(size_t)m * stride];
+    return cell_dp(c) - cell_x(c);
+}
+
+// Does some proper suffix of B equal a prefix of A?  (Precondition of a free
+// traceback when B is not a subpath of A and m <= n.)
+__device__ bool has_overhang(const StepsA &A, const StepsB &B)
+{
+    const int m = B.m;
+    for (int len = 1; len <= m - 1 && len <= A.n; ++len) {
+        bool eq = true;
+        for (int k = 0; eq && k < len; ++k)
+            eq = (uint32_t)A.step[k] == B.at(m - len + k);
+        if (eq) return true;
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(DP_THREADS) void k_dp(
+    Items items, const uint16_t *__restrict__ images, ImageLayout L, int n_paths,
+    const unsigned long long *__restrict__ worklist,
+    const uint32_t *__restrict__ wl_count, uint32_t wl_capacity,
+    uint32_t *__restrict__ row_scratch, uint32_t *__restrict__ counts)
+{
+    const int stride = gridDim.x * DP_THREADS;
+    const int gtid = blockIdx.x * DP_THREADS + threadIdx.x;
+    uint32_t *row = row_scratch + gtid;
+    const uint32_t total = min(*wl_count, wl_capacity);
+    for (uint32_t w = gtid; w < total; w += stride) {
+        const unsigned long long ent = worklist[w];
+        const uint32_t p = (uint32_t)(ent >> 32);
+        const uint32_t slot = (uint32_t)ent;
+        const uint32_t it = slot >> 6, ln = slot & 63u;
+        const uint16_t *img = images + (size_t)p * L.total;
+        StepsA A{img + L.step_at(), (int)img[L.len_at()]};
+        StepsB B{items.steps + (size_t)items.base[it] * WAVE + ln,
+                 (int)items.len[it], 0u};
+        bool good = false;
+        for (uint32_t flip = 0; flip < 2 && !good; ++flip) {
+            B.flip = flip;
+            if (has_overhang(A, B)) good = traceback_score(A, B, row, stride) == 0;
+        }
+        atomicAdd(&counts[(good ? n_paths : 0) + p], 1u);
+    }
+}
+
+__global__ __launch_bounds__(DP_THREADS) void k_pairs(
+    Items items, const int32_t *__restrict__ slot_orig,
+    const uint16_t *__restrict__ image, ImageLayout L,
+    uint32_t *__restrict__ row_scratch, int32_t *__restrict__ fw,
+    int32_t *__restrict__ rc)
+{
+    const int stride = gridDim.x * DP_THREADS;
+    const int gtid = blockIdx.x * DP_THREADS + threadIdx.x;
+    uint32_t *row = row_scratch + gtid;
+    const long long n_slots = (long long)items.n_items * WAVE;
+    StepsA A{image + L.step_at(), (int)image[L.len_at()]};
+    for (long long s = gtid; s < n_slots; s += stride) {
+        const int32_t orig = slot_orig[s];
+        if (orig < 0) continue;
+        const uint32_t it = (uint32_t)(s >> 6), ln = (uint32_t)(s & 63);
+        StepsB B{items.steps + (size_t)items.base[it] * WAVE + ln,
+                 (int)items.len[it], 0u};
+        fw[orig] = traceback_score(A, B, row, stride);
+        B.flip = 1u;
+        rc[orig] = traceback_score(A, B, row, stride);
+    }
+}
+
+__global__ void k_fill_i32(int32_t *p, long long n, int32_t v)
+{
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+}  // namespace
+
+// --------------------------------------------------------------------------
+// host side
+// --------------------------------------------------------------------------
+struct gfal_scorer {
+    int device = 0;
+    int64_t n_aln = 0, n_steps = 0;
+    int32_t n_nodes = 0, n_local = 0, max_aln_len = 0;
+    uint32_t n_empty = 0;
+    int n_items = 0;
+    int64_t n_item_u16 = 0;
+
+    // device, owned
+    int32_t *d_node_local = nullptr;   // [n_nodes] -> local id or -1
+    uint32_t *d_node_hist = nullptr;   // [n_local] alignment steps per node
+    uint16_t *d_item_steps = nullptr;
+    uint32_t *d_item_base = nullptr;
+    uint16_t *d_item_len = nullptr;
+    int32_t *d_slot_orig = nullptr;    // [n_items*64] original index or -1
+    uint32_t *d_status = nullptr;      // [2]: status word, worklist count
+    unsigned long long *d_worklist = nullptr;
+    uint32_t wl_capacity = 0;
+    uint32_t *d_rows = nullptr;        // DP row scratch
+    uint16_t *d_images = nullptr;
+    size_t images_cap = 0;             // uint16 units
+
+    // blocking-API staging
+    int32_t *d_path_off = nullptr, *d_path_steps = nullptr;
+    uint32_t *d_counts = nullptr;
+    size_t path_off_cap = 0, path_steps_cap = 0, counts_cap = 0;
+    hipStream_t stream = nullptr;      // owned, for the blocking API
+
+    // last call
+    hipStream_t last_stream = nullptr;
+    bool have_last = false;
+    int last_tile = 0, last_grid = 0, last_lds = 0;
+    bool profiling = false;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool ev_valid = false;
+};
+
+namespace {
+
+template <typename T>
+int dev_upload(T **dst, const std::vector<T> &src)
+{
+    size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(dst), bytes));
+    if (!src.empty())
+        HIP_TRY(hipMemcpy(*dst, src.data(), src.size() * sizeof(T),
+                          hipMemcpyHostToDevice));
+    return GFAL_OK;
+}
+
+template <typename T>
+int dev_reserve(T **buf, size_t *cap, size_t want)
+{
+    if (want <= *cap && *buf) return GFAL_OK;
+    if (*buf) HIP_TRY(hipFree(*buf));
+    *buf = nullptr;
+    size_t grow = std::max<size_t>(want, 1);
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(buf), grow * sizeof(T)));
+    *cap = grow;
+    return GFAL_OK;
+}
+
+void free_scorer(gfal_scorer *s)
+{
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    void *bufs[] = {s->d_node_local, s->d_node_hist, s->d_item_steps, s->d_item_base,
+                    s->d_item_len,   s->d_slot_orig, s->d_status,     s->d_worklist,
+                    s->d_rows,       s->d_images,    s->d_path_off,   s->d_path_steps,
+                    s->d_counts};
+    for (void *b : bufs)
+        if (b) (void)hipFree(b);
+    for (hipEvent_t e : s->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+
+int row_scratch_words(int max_aln_len)
+{
+    return (max_aln_len + 1) * DP_BLOCKS * DP_THREADS;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gfal_abi_version(void) { return GFAL_ABI_VERSION; }
+
+const char *gfal_strerror(int code)
+{
+    switch (code) {
+    case GFAL_OK: return "ok";
+    case GFAL_E_ARG: return "invalid argument";
+    case GFAL_E_RANGE: return "path/alignment length or node id out of range";
+    case GFAL_E_NO_DEVICE: return "no usable HIP device";
+    case GFAL_E_HIP: return "HIP runtime error";
+    case GFAL_E_NOMEM: return "out of memory";
+    default: return "unknown error";
+    }
+}
+
+const char *gfal_last_error(void) { return g_err; }
+
+int gfal_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        set_err("hipGetDeviceCount: %s", hipGetErrorString(e));
+        return GFAL_E_NO_DEVICE;
+    }
+    return n;
+}
+
+int gfal_scorer_create(const int32_t *aln_off, const int32_t *aln_steps,
+                       int64_t n_aln, int32_t n_nodes, int device,
+                       gfal_scorer **out)
+{
+    if (!out) return GFAL_E_ARG;
+    *out = nullptr;
+    if (n_aln < 0 || n_nodes < 0 || (n_aln > 0 && (!aln_off || aln_off[0] != 0)))
+        return GFAL_E_ARG;
+    if (n_aln >= (int64_t)1 << 31) return GFAL_E_RANGE;
+    const int64_t S = n_aln ? aln_off[n_aln] : 0;
+    if (S < 0 || (S > 0 && !aln_steps)) return GFAL_E_ARG;
+
+    int ndev = gfal_device_count();
+    if (ndev <= 0 || device < 0 || device >= ndev) {
+        if (ndev >= 0) set_err("device %d requested, %d visible", device, ndev);
+        return GFAL_E_NO_DEVICE;
+    }
+
+    // ---- validate, find the nodes that occur, bucket by length ----
+    std::vector<int32_t> node_local((size_t)n_nodes, -1);
+    int max_len = 0;
+    uint32_t n_empty = 0;
+    for (int64_t k = 0; k < n_aln; ++k) {
+        int64_t m = (int64_t)aln_off[k + 1] - aln_off[k];
+        if (m < 0 || aln_off[k + 1] > S) return GFAL_E_ARG;
+        if (m > GFAL_MAX_STEPS) {
+            set_err("alignment %lld has %lld steps (max %d)", (long long)k,
+                    (long long)m, GFAL_MAX_STEPS);
+            return GFAL_E_RANGE;
+        }
+        if (m == 0) ++n_empty;
+        max_len = std::max(max_len, (int)m);
+    }
+    for (int64_t t = 0; t < S; ++t) {
+        int32_t s = aln_steps[t];
+        if (s < 0 || (s >> 1) >= n_nodes) {
+            set_err("alignment step %lld: node id out of range", (long long)t);
+            return GFAL_E_RANGE;
+        }
+        node_local[s >> 1] = 0;
+    }
+    int n_local = 0;
+    for (int32_t v = 0; v < n_nodes; ++v)
+        if (node_local[v] == 0) node_local[v] = n_local++;
+    if (n_local > MAX_LOCAL_NODES) {
+        set_err("%d distinct nodes in the alignments; this build stages at most %d",
+                n_local, MAX_LOCAL_NODES);
+        return GFAL_E_RANGE;
+    }
+    std::vector<uint32_t> hist((size_t)n_local, 0);
+    std::vector<uint16_t> local_steps((size_t)S);
+    for (int64_t t = 0; t < S; ++t) {
+        int32_t s = aln_steps[t];
+        uint32_t lid = (uint32_t)node_local[s >> 1];
+        ++hist[lid];
+        local_steps[(size_t)t] = (uint16_t)((lid << 1) | ((uint32_t)s & 1u));
+    }
+
+    // alignments of one length together, ordered by content so the lanes of a
+    // wave look at neighbouring table entries and take the same branches
+    std::vector<std::vector<int32_t>> by_len((size_t)max_len + 1);
+    for (int64_t k = 0; k < n_aln; ++k) {
+        int m = aln_off[k + 1] - aln_off[k];
+        if (m > 0) by_len[(size_t)m].push_back((int32_t)k);
+    }
+    std::vector<uint16_t> item_steps;
+    std::vector<uint32_t> item_base;
+    std::vector<uint16_t> item_len;
+    std::vector<int32_t> slot_orig;
+    item_steps.reserve((size_t)S + 64 * 64);
+    for (int m = 1; m <= max_len; ++m) {
+        std::vector<int32_t> &idx = by_len[(size_t)m];
+        if (idx.empty()) continue;
+        const uint16_t *ls = local_steps.data();
+        std::sort(idx.begin(), idx.end(), [&](int32_t x, int32_t y) {
+            const uint16_t *px = ls + aln_off[x], *py = ls + aln_off[y];
+            for (int t = 0; t < m; ++t)
+                if (px[t] != py[t]) return px[t] < py[t];
+            return x < y;
+        });
+        for (size_t at = 0; at < idx.size(); at += WAVE) {
+            size_t cnt = std::min<size_t>(WAVE, idx.size() - at);
+            size_t base = item_steps.size();
+            item_base.push_back((uint32_t)(base / WAVE));
+            item_len.push_back((uint16_t)m);
+            item_steps.resize(base + (size_t)m * WAVE, (uint16_t)STEP_INVALID);
+            for (size_t l = 0; l < WAVE; ++l) {
+                if (l < cnt) {
+                    const uint16_t *px = ls + aln_off[idx[at + l]];
+                    for (int t = 0; t < m; ++t)
+                        item_steps[base + (size_t)t * WAVE + l] = px[t];
+                    slot_orig.push_back(idx[at + l]);
+                } else {
+                    slot_orig.push_back(-1);
+                }
+            }
+        }
+    }
+    if (item_steps.size() / WAVE >= ((uint64_t)1 << 32) ||
+        item_base.size() >= ((size_t)1 << 25)) {
+        set_err("shard too large for 32-bit item addressing");
+        return GFAL_E_RANGE;
+    }
+
+    gfal_scorer *s = new (std::nothrow) gfal_scorer();
+    if (!s) return GFAL_E_NOMEM;
+    s->device = device;
+    s->n_aln = n_aln;
+    s->n_steps = S;
+    s->n_nodes = n_nodes;
+    s->n_local = n_local;
+    s->max_aln_len = max_len;
+    s->n_empty = n_empty;
+    s->n_items = (int)item_base.size();
+    s->n_item_u16 = (int64_t)item_steps.size();
+
+    int rc = GFAL_OK;
+    auto fail = [&](int code) {
+        free_scorer(s);
+        return code;
+    };
+#define CREATE_TRY(expr)                                                       \
+    do {                                                                       \
+        hipError_t e_ = (expr);                                                \
+        if (e_ != hipSuccess) {                                                \
+            set_err("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),     \
+                    __FILE__, __LINE__);                                       \
+            return fail(e_ == hipErrorOutOfMemory ? GFAL_E_NOMEM : GFAL_E_HIP); \
+        }                                                                      \
+    } while (0)
+    CREATE_TRY(hipSetDevice(device));
+    CREATE_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    // both kernels may ask for more than the default 64 KiB of dynamic LDS
+    CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   LDS_BUDGET));
+    CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_prep),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   LDS_BUDGET + 2 * (GFAL_MAX_STEPS + 2)));
+    if ((rc = dev_upload(&s->d_node_local, node_local))) return fail(rc);
+    if ((rc = dev_upload(&s->d_node_hist, hist))) return fail(rc);
+    if ((rc = dev_upload(&s->d_item_steps, item_steps))) return fail(rc);
+    if ((rc = dev_upload(&s->d_item_base, item_base))) return fail(rc);
+    if ((rc = dev_upload(&s->d_item_len, item_len))) return fail(rc);
+    if ((rc = dev_upload(&s->d_slot_orig, slot_orig))) return fail(rc);
+    CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_status), 2 * sizeof(uint32_t)));
+    CREATE_TRY(hipMemset(s->d_status, 0, 2 * sizeof(uint32_t)));
+    // worklist: at least one entry per alignment, so a single path always fits
+    s->wl_capacity = (uint32_t)std::max<int64_t>(n_aln, (int64_t)1 << 22);
+    CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_worklist),
+                         (size_t)s->wl_capacity * sizeof(unsigned long long)));
+    CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_rows),
+                         (size_t)row_scratch_words(max_len) * sizeof(uint32_t)));
+    for (hipEvent_t &e : s->ev) CREATE_TRY(hipEventCreate(&e));
+#undef CREATE_TRY
+    *out = s;
+    return GFAL_OK;
+}
+
+void gfal_scorer_destroy(gfal_scorer *s) { free_scorer(s); }
+
+int gfal_scorer_set_profiling(gfal_scorer *s, int enable)
+{
+    if (!s) return GFAL_E_ARG;
+    s->profiling = enable != 0;
+    s->ev_valid = false;
+    return GFAL_OK;
+}
+
+int gfal_scorer_score_device(gfal_scorer *s, const int32_t *d_path_off,
+                             const int32_t *d_path_steps, int32_t n_paths,
+                             int64_t total_steps, int32_t max_path_len, int filter,
+                             uint32_t *d_counts, void *hip_stream)
+{
+    if (!s || n_paths < 0 || total_steps < 0) return GFAL_E_ARG;
+    if (n_paths == 0) return GFAL_OK;
+    if (!d_path_off || !d_path_steps || !d_counts) return GFAL_E_ARG;
+    if (max_path_len < 1 || max_path_len > GFAL_MAX_STEPS) return GFAL_E_RANGE;
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    HIP_TRY(hipSetDevice(s->device));
+
+    const ImageLayout L = make_layout(s->n_local, max_path_len);
+    const size_t img_bytes = (size_t)L.total * sizeof(uint16_t);
+    if (img_bytes > (size_t)LDS_BUDGET) {
+        set_err("path image of %zu bytes exceeds the LDS budget", img_bytes);
+        return GFAL_E_RANGE;
+    }
+    {
+        size_t want = (size_t)n_paths * L.total;
+        if (want > s->images_cap) {
+            // growing the image pool must not race with an earlier call
+            if (s->have_last) HIP_TRY(hipStreamSynchronize(s->last_stream));
+            int rc = dev_reserve(&s->d_images, &s->images_cap, want);
+            if (rc) return rc;
+        }
+    }
+
+    HIP_TRY(hipMemsetAsync(s->d_status, 0, 2 * sizeof(uint32_t), st));
+    if (s->profiling) HIP_TRY(hipEventRecord(s->ev[0], st));
+
+    const size_t prep_lds = img_bytes + (size_t)L.nm * sizeof(uint16_t);
+    hipLaunchKernelGGL(k_prep, dim3((unsigned)n_paths), dim3(WAVE), prep_lds, st,
+                       d_path_off, d_path_steps, (int)n_paths, total_steps,
+                       (int)max_path_len, s->d_node_local, (int)s->n_nodes,
+                       s->d_node_hist, (uint32_t)s->n_steps, s->n_empty, filter, L,
+                       s->d_images, d_counts, s->d_status);
+    HIP_TRY(hipGetLastError());
+    if (s->profiling) HIP_TRY(hipEventRecord(s->ev[1], st));
+
+    s->last_tile = 0;
+    s->last_grid = 0;
+    s->last_lds = 0;
+    if (s->n_items > 0) {
+        ScanArgs a;
+        a.items = Items{s->d_item_steps, s->d_item_base, s->d_item_len, s->n_items};
+        a.images = s->d_images;
+        a.L = L;
+        a.n_paths = n_paths;
+        int tile = (int)std::min<size_t>((size_t)LDS_BUDGET / img_bytes, MAX_TILE);
+        tile = std::max(1, std::min(tile, (int)n_paths));
+        a.tile = tile;
+        a.n_tiles = (n_paths + tile - 1) / tile;
+        // enough workgroups to fill 256 CUs x 2 several times over, but every
+        // chunk keeps a few items per wave
+        const int want_groups = 4096;
+        int chunks = (want_groups + a.n_tiles - 1) / a.n_tiles;
+        const int max_chunks = std::max(1, s->n_items / (2 * SCAN_WAVES));
+        chunks = std::max(1, std::min(chunks, max_chunks));
+        chunks = (chunks + 7) & ~7;
+        a.n_chunks = chunks;
+        a.items_per_chunk = (s->n_items + chunks - 1) / chunks;
+        a.filter = filter ? 1 : 0;
+        a.counts = d_counts;
+        a.worklist = s->d_worklist;
+        a.wl_count = s->d_status + 1;
+        a.wl_capacity = s->wl_capacity;
+        a.status = s->d_status;
+        const size_t lds = std::max((size_t)tile * img_bytes,
+                                    (size_t)2 * MAX_TILE * sizeof(uint32_t));
+        const unsigned grid = (unsigned)a.n_tiles * (unsigned)a.n_chunks;
+        hipLaunchKernelGGL(k_scan, dim3(grid), dim3(SCAN_THREADS), lds, st, a);
+        HIP_TRY(hipGetLastError());
+        s->last_tile = tile;
+        s->last_grid = (int)grid;
+        s->last_lds = (int)lds;
+        if (s->profiling) HIP_TRY(hipEventRecord(s->ev[2], st));
+
+        hipLaunchKernelGGL(k_dp, dim3(DP_BLOCKS), dim3(DP_THREADS), 0, st, a.items,
+                           s->d_images, L, (int)n_paths, s->d_worklist,
+                           s->d_status + 1, s->wl_capacity, s->d_rows, d_counts);
+        HIP_TRY(hipGetLastError());
+    } else if (s->profiling) {
+        HIP_TRY(hipEventRecord(s->ev[2], st));
+    }
+    if (s->profiling) {
+        HIP_TRY(hipEventRecord(s->ev[3], st));
+        s->ev_valid = true;
+    }
+    s->last_stream = st;
+    s->have_last = true;
+    return GFAL_OK;
+}
+
+int gfal_scorer_sync_status(gfal_scorer *s)
+{
+    if (!s) return GFAL_E_ARG;
+    if (!s->have_last) return GFAL_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    uint32_t host[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(host, s->d_status, sizeof(host), hipMemcpyDeviceToHost,
+                           s->last_stream));
+    HIP_TRY(hipStreamSynchronize(s->last_stream));
+    if (host[0] & (ST_BAD_LEN | ST_BAD_ID)) {
+        set_err("device-side validation failed (status 0x%x)", host[0]);
+        return GFAL_E_RANGE;
+    }
+    if (host[0] & ST_DP_OVERFLOW) {
+        set_err("exact-DP worklist overflow (%u pairs, capacity %u): split the batch",
+                host[1], s->wl_capacity);
+        return GFAL_E_NOMEM;
+    }
+    return GFAL_OK;
+}
+
+static int score_range(gfal_scorer *s, const int32_t *path_off,
+                       const int32_t *path_steps, int32_t lo, int32_t hi,
+                       int32_t max_len, int filter, uint32_t *bad, uint32_t *good,
+                       uint32_t *unaligned)
+{
+    const int32_t P = hi - lo;
+    const int64_t step0 = path_off[lo];
+    const int64_t total = path_off[hi] - step0;
+    int rc;
+    if ((rc = dev_reserve(&s->d_path_off, &s->path_off_cap, (size_t)P + 1))) return rc;
+    if ((rc = dev_reserve(&s->d_path_steps, &s->path_steps_cap, (size_t)total))) return rc;
+    if ((rc = dev_reserve(&s->d_counts, &s->counts_cap, (size_t)3 * P))) return rc;
+    std::vector<int32_t> off((size_t)P + 1);
+    for (int32_t i = 0; i <= P; ++i) off[(size_t)i] = (int32_t)(path_off[lo + i] - step0);
+    HIP_TRY(hipMemcpyAsync(s->d_path_off, off.data(), off.size() * sizeof(int32_t),
+                           hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->d_path_steps, path_steps + step0,
+                           (size_t)total * sizeof(int32_t), hipMemcpyHostToDevice,
+                           s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));   // `off` is a local
+    rc = gfal_scorer_score_device(s, s->d_path_off, s->d_path_steps, P, total, max_len,
+                                  filter, s->d_counts, s->stream);
+    if (rc) return rc;
+    rc = gfal_scorer_sync_status(s);
+    if (rc == GFAL_E_NOMEM && P > 1) {
+        // worklist overflow: halve the batch (a single path always fits)
+        int32_t mid = lo + P / 2;
+        rc = score_range(s, path_off, path_steps, lo, mid, max_len, filter, bad, good,
+                         unaligned);
+        if (rc) return rc;
+        return score_range(s, path_off, path_steps, mid, hi, max_len, filter, bad, good,
+                           unaligned);
+    }
+    if (rc) return rc;
+    std::vector<uint32_t> host((size_t)3 * P);
+    HIP_TRY(hipMemcpy(host.data(), s->d_counts, host.size() * sizeof(uint32_t),
+                      hipMemcpyDeviceToHost));
+    for (int32_t i = 0; i < P; ++i) {
+        bad[lo + i] = host[(size_t)i];
+        good[lo + i] = host[(size_t)P + i];
+        if (unaligned) unaligned[lo + i] = host[(size_t)2 * P + i];
+    }
+    return GFAL_OK;
+}
+
+int gfal_scorer_score(gfal_scorer *s, const int32_t *path_off,
+                      const int32_t *path_steps, int32_t n_paths, int filter,
+                      uint32_t *bad, uint32_t *good, uint32_t *unaligned)
+{
+    if (!s || n_paths < 0) return GFAL_E_ARG;
+    if (n_paths == 0) return GFAL_OK;
+    if (!path_off || !path_steps || !bad || !good || path_off[0] != 0) return GFAL_E_ARG;
+    int32_t max_len = 1;
+    for (int32_t p = 0; p < n_paths; ++p) {
+        int64_t n = (int64_t)path_off[p + 1] - path_off[p];
+        if (n < 1 || n > GFAL_MAX_STEPS) {
+            set_err("path %d has %lld steps (allowed 1..%d)", p, (long long)n,
+                    GFAL_MAX_STEPS);
+            return GFAL_E_RANGE;
+        }
+        max_len = std::max(max_len, (int32_t)n);
+    }
+    for (int64_t t = 0; t < path_off[n_paths]; ++t) {
+        int32_t st = path_steps[t];
+        if (st < 0 || ((st & ~GFAL_STEP_OTHER) >> 1) >= s->n_nodes) {
+            set_err("path step %lld: node id out of range", (long long)t);
+            return GFAL_E_RANGE;
+        }
+    }
+    HIP_TRY(hipSetDevice(s->device));
+    return score_range(s, path_off, path_steps, 0, n_paths, max_len, filter, bad, good,
+                       unaligned);
+}
+
+int gfal_scorer_pair_scores(gfal_scorer *s, const int32_t *path_steps, int32_t n,
+                            int32_t *fw, int32_t *rc_out)
+{
+    if (!s || !path_steps || !fw || !rc_out) return GFAL_E_ARG;
+    if (n < 1 || n > GFAL_MAX_STEPS) return GFAL_E_RANGE;
+    for (int32_t i = 0; i < n; ++i) {
+        int32_t st = path_steps[i];
+        if (st < 0 || ((st & ~GFAL_STEP_OTHER) >> 1) >= s->n_nodes) return GFAL_E_RANGE;
+    }
+    HIP_TRY(hipSetDevice(s->device));
+    if (s->n_aln == 0) return GFAL_OK;
+    const ImageLayout L = make_layout(s->n_local, n);
+    const size_t img_bytes = (size_t)L.total * sizeof(uint16_t);
+    if (img_bytes > (size_t)LDS_BUDGET) return GFAL_E_RANGE;
+    int rc;
+    if (s->have_last) HIP_TRY(hipStreamSynchronize(s->last_stream));
+    if ((rc = dev_reserve(&s->d_images, &s->images_cap, (size_t)L.total))) return rc;
+    if ((rc = dev_reserve(&s->d_path_off, &s->path_off_cap, 2))) return rc;
+    if ((rc = dev_reserve(&s->d_path_steps, &s->path_steps_cap, (size_t)n))) return rc;
+    if ((rc = dev_reserve(&s->d_counts, &s->counts_cap, 3))) return rc;
+    int32_t off[2] = {0, n};
+    HIP_TRY(hipMemcpy(s->d_path_off, off, sizeof(off), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->d_path_steps, path_steps, (size_t)n * sizeof(int32_t),
+                      hipMemcpyHostToDevice));
+    HIP_TRY(hipMemsetAsync(s->d_status, 0, 2 * sizeof(uint32_t), s->stream));
+    const size_t prep_lds = img_bytes + (size_t)L.nm * sizeof(uint16_t);
+    hipLaunchKernelGGL(k_prep, dim3(1), dim3(WAVE), prep_lds, s->stream, s->d_path_off,
+                       s->d_path_steps, 1, (int64_t)n, (int)n, s->d_node_local,
+                       (int)s->n_nodes, s->d_node_hist, (uint32_t)s->n_steps,
+                       s->n_empty, 0, L, s->d_images, s->d_counts, s->d_status);
+    HIP_TRY(hipGetLastError());
+
+    int32_t *d_fw = nullptr, *d_rc = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_fw), (size_t)s->n_aln * sizeof(int32_t)));
+    hipError_t e2 = hipMalloc(reinterpret_cast<void **>(&d_rc),
+                              (size_t)s->n_aln * sizeof(int32_t));
+    if (e2 != hipSuccess) {
+        (void)hipFree(d_fw);
+        set_err("hipMalloc failed: %s", hipGetErrorString(e2));
+        return GFAL_E_NOMEM;
+    }
+    // zero-step alignments: both tracebacks are free (score 0)
+    unsigned fill_blocks = (unsigned)((s->n_aln + 255) / 256);
+    hipLaunchKernelGGL(k_fill_i32, dim3(fill_blocks), dim3(256), 0, s->stream, d_fw,
+                       (long long)s->n_aln, 0);
+    hipLaunchKernelGGL(k_fill_i32, dim3(fill_blocks), dim3(256), 0, s->stream, d_rc,
+                       (long long)s->n_aln, 0);
+    if (s->n_items > 0) {
+        Items items{s->d_item_steps, s->d_item_base, s->d_item_len, s->n_items};
+        hipLaunchKernelGGL(k_pairs, dim3(DP_BLOCKS), dim3(DP_THREADS), 0, s->stream,
+                           items, s->d_slot_orig, s->d_images, L, s->d_rows, d_fw, d_rc);
+    }
+    hipError_t e3 = hipGetLastError();
+    if (e3 == hipSuccess)
+        e3 = hipMemcpyAsync(fw, d_fw, (size_t)s->n_aln * sizeof(int32_t),
+                            hipMemcpyDeviceToHost, s->stream);
+    if (e3 == hipSuccess)
+        e3 = hipMemcpyAsync(rc_out, d_rc, (size_t)s->n_aln * sizeof(int32_t),
+                            hipMemcpyDeviceToHost, s->stream);
+    if (e3 == hipSuccess) e3 = hipStreamSynchronize(s->stream);
+    (void)hipFree(d_fw);
+    (void)hipFree(d_rc);
+    if (e3 != hipSuccess) {
+        set_err("pair_scores: %s", hipGetErrorString(e3));
+        return GFAL_E_HIP;
+    }
+    s->last_stream = s->stream;
+    s->have_last = true;
+    return gfal_scorer_sync_status(s);
+}
+
+int gfal_scorer_get_info(gfal_scorer *s, gfal_info *out)
+{
+    if (!s || !out) return GFAL_E_ARG;
+    memset(out, 0, sizeof(*out));
+    out->n_aln = s->n_aln;
+    out->n_steps = s->n_steps;
+    out->n_nodes = s->n_nodes;
+    out->n_local_nodes = s->n_local;
+    out->max_aln_len = s->max_aln_len;
+    out->tile_paths = s->last_tile;
+    out->n_workgroups = s->last_grid;
+    out->lds_bytes = s->last_lds;
+    if (s->have_last) {
+        HIP_TRY(hipSetDevice(s->device));
+        uint32_t host[2] = {0, 0};
+        HIP_TRY(hipMemcpyAsync(host, s->d_status, sizeof(host), hipMemcpyDeviceToHost,
+                               s->last_stream));
+        HIP_TRY(hipStreamSynchronize(s->last_stream));
+        out->dp_pairs = host[1];
+        if (s->profiling && s->ev_valid) {
+            HIP_TRY(hipEventSynchronize(s->ev[3]));
+            float t = 0.f;
+            HIP_TRY(hipEventElapsedTime(&t, s->ev[1], s->ev[2]));
+            out->scan_ms = t;
+            HIP_TRY(hipEventElapsedTime(&t, s->ev[2], s->ev[3]));
+            out->dp_ms = t;
+            HIP_TRY(hipEventElapsedTime(&t, s->ev[0], s->ev[3]));
+            out->total_ms = t;
+        }
+    }
+    return GFAL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,183 @@
+"""Host-side binding of the C ABI in include/gfalign_scorer.h (ctypes).
+
+Mirrors the one seam the reference has on this path -- ``evaluatePath``
+(reference src/eval.cpp:67-108) -- as :meth:`Scorer.evaluate_paths`.  There is
+no CPU fallback here: if ``libgfalign_scorer.so`` is missing or no HIP device
+is usable, construction raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import build as _build
+
+GFAL_MAX_STEPS = 1000
+GFAL_STEP_OTHER = 0x40000000
+
+_i32p = ctypes.POINTER(ctypes.c_int32)
+_u32p = ctypes.POINTER(ctypes.c_uint32)
+
+
+class GfalInfo(ctypes.Structure):
+    _fields_ = [("n_aln", ctypes.c_int64), ("n_steps", ctypes.c_int64),
+                ("n_nodes", ctypes.c_int32), ("n_local_nodes", ctypes.c_int32),
+                ("max_aln_len", ctypes.c_int32), ("tile_paths", ctypes.c_int32),
+                ("n_workgroups", ctypes.c_int32), ("lds_bytes", ctypes.c_int32),
+                ("dp_pairs", ctypes.c_int64), ("scan_ms", ctypes.c_float),
+                ("dp_ms", ctypes.c_float), ("total_ms", ctypes.c_float)]
+
+
+# every symbol include/gfalign_scorer.h declares
+EXPORTS = {
+    "gfal_abi_version": (ctypes.c_int, []),
+    "gfal_strerror": (ctypes.c_char_p, [ctypes.c_int]),
+    "gfal_last_error": (ctypes.c_char_p, []),
+    "gfal_device_count": (ctypes.c_int, []),
+    "gfal_scorer_create": (ctypes.c_int, [_i32p, _i32p, ctypes.c_int64, ctypes.c_int32,
+                                          ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    "gfal_scorer_destroy": (None, [ctypes.c_void_p]),
+    "gfal_scorer_score": (ctypes.c_int, [ctypes.c_void_p, _i32p, _i32p, ctypes.c_int32,
+                                         ctypes.c_int, _u32p, _u32p, _u32p]),
+    "gfal_scorer_score_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p,
+                                                ctypes.c_void_p, ctypes.c_int32,
+                                                ctypes.c_int64, ctypes.c_int32,
+                                                ctypes.c_int, ctypes.c_void_p,
+                                                ctypes.c_void_p]),
+    "gfal_scorer_sync_status": (ctypes.c_int, [ctypes.c_void_p]),
+    "gfal_scorer_pair_scores": (ctypes.c_int, [ctypes.c_void_p, _i32p, ctypes.c_int32,
+                                               _i32p, _i32p]),
+    "gfal_scorer_set_profiling": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "gfal_scorer_get_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(GfalInfo)]),
+}
+
+_lib = None
+
+
+class ScorerError(RuntimeError):
+    def __init__(self, code, what):
+        self.code = code
+        super().__init__(what)
+
+
+def library_path():
+    return _build.SCORER_SO
+
+
+def load_library():
+    """dlopen the in-tree shared library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise ScorerError(-3, "%s is missing: run `python -m gfalign_amd.build` "
+                                  "(there is no CPU fallback)" % path)
+        lib = ctypes.CDLL(path)
+        for name, (res, args) in EXPORTS.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def _check(code):
+    if code != 0:
+        lib = load_library()
+        msg = lib.gfal_strerror(code).decode()
+        detail = lib.gfal_last_error().decode()
+        raise ScorerError(code, "%s%s" % (msg, (": " + detail) if detail else ""))
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _ptr(a, ty):
+    return a.ctypes.data_as(ctypes.POINTER(ty))
+
+
+def pack_step(node_id, orientation):
+    """Reference Step{id, orientation} -> packed int32 (see the header)."""
+    if orientation == "+":
+        return node_id << 1
+    if orientation == "-":
+        return (node_id << 1) | 1
+    return GFAL_STEP_OTHER | (node_id << 1)
+
+
+class Scorer:
+    """One shard of alignments resident on one MI355X."""
+
+    def __init__(self, aln_off, aln_steps, n_nodes, device=0):
+        self._lib = load_library()
+        self._h = ctypes.c_void_p()
+        aln_off, aln_steps = _i32(aln_off), _i32(aln_steps)
+        self.n_aln = len(aln_off) - 1
+        _check(self._lib.gfal_scorer_create(
+            _ptr(aln_off, ctypes.c_int32), _ptr(aln_steps, ctypes.c_int32),
+            self.n_aln, int(n_nodes), int(device), ctypes.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            self._lib.gfal_scorer_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def evaluate_paths(self, path_off, path_steps, filter=True, want_unaligned=True):
+        """evaluatePath (src/eval.cpp:67-108) per path -> (bad, good, unaligned)."""
+        path_off, path_steps = _i32(path_off), _i32(path_steps)
+        P = len(path_off) - 1
+        bad = np.zeros(P, np.uint32)
+        good = np.zeros(P, np.uint32)
+        una = np.zeros(P, np.uint32) if want_unaligned else None
+        _check(self._lib.gfal_scorer_score(
+            self._h, _ptr(path_off, ctypes.c_int32), _ptr(path_steps, ctypes.c_int32),
+            P, int(bool(filter)), _ptr(bad, ctypes.c_uint32), _ptr(good, ctypes.c_uint32),
+            _ptr(una, ctypes.c_uint32) if want_unaligned else None))
+        return bad, good, una
+
+    def score_device(self, d_path_off, d_path_steps, n_paths, total_steps,
+                     max_path_len, filter, d_counts, stream=0):
+        """Async form on raw device pointers (ints); see the header."""
+        _check(self._lib.gfal_scorer_score_device(
+            self._h, ctypes.c_void_p(d_path_off), ctypes.c_void_p(d_path_steps),
+            int(n_paths), int(total_steps), int(max_path_len), int(bool(filter)),
+            ctypes.c_void_p(d_counts), ctypes.c_void_p(stream)))
+
+    def sync_status(self):
+        _check(self._lib.gfal_scorer_sync_status(self._h))
+
+    def pair_scores(self, path_steps):
+        """(fw, rc) traceback scores of every alignment vs one path."""
+        path_steps = _i32(path_steps)
+        fw = np.zeros(self.n_aln, np.int32)
+        rc = np.zeros(self.n_aln, np.int32)
+        _check(self._lib.gfal_scorer_pair_scores(
+            self._h, _ptr(path_steps, ctypes.c_int32), len(path_steps),
+            _ptr(fw, ctypes.c_int32), _ptr(rc, ctypes.c_int32)))
+        return fw, rc
+
+    def set_profiling(self, on=True):
+        _check(self._lib.gfal_scorer_set_profiling(self._h, int(bool(on))))
+
+    def info(self):
+        out = GfalInfo()
+        _check(self._lib.gfal_scorer_get_info(self._h, ctypes.byref(out)))
+        return {name: getattr(out, name) for name, _ in GfalInfo._fields_}
+
+
+def device_count():
+    n = load_library().gfal_device_count()
+    return max(n, 0)

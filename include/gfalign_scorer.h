@@ -1,0 +1,155 @@
+/*
+ * gfalign_scorer.h -- C ABI of the MI355X path scorer (libgfalign_scorer.so).
+ *
+ * Drop-in boundary for the one seam the reference has on this path: the
+ * internal C++ call
+ *     PathAlignmentStats evaluatePath(const Path &path, InSequences &,
+ *                                     std::vector<Path> alignmentPaths,
+ *                                     bool filterAlignments, bool printAlignments)
+ * (reference src/eval.cpp:67-108), called from the search loop
+ * (src/eval.cpp:162, filter=true) and from evalPath (src/eval.cpp:238,
+ * filter=false, print=true).  The reference has no FFI, so the entry points
+ * below are the ones a binding for that call would need; INTEGRATION.md shows
+ * the patch a reference maintainer would apply.
+ *
+ * Plain pointers and sizes only.  All functions return 0 on success or a
+ * negative GFAL_E_* code; nothing throws or exits across this boundary.
+ * A scorer is bound to one HIP device and is used from one host thread at a
+ * time.  There is no CPU fallback: without a usable HIP device
+ * gfal_scorer_create fails with GFAL_E_NO_DEVICE.
+ *
+ * Step encoding ("packed step", int32):
+ *     (node_id << 1) | minus            node_id in [0, n_nodes), minus in {0,1}
+ * reference Step{id, orientation} (include/alignments.h:11-21) with '+' -> 0,
+ * '-' -> 1.  A candidate-path step whose orientation is neither '+' nor '-'
+ * (the reference compares the raw char, so such a step equals no alignment
+ * step but its node still counts for the filter; include/alignments.h:15-17,
+ * src/eval.cpp:76-78) is passed as  GFAL_STEP_OTHER | (node_id << 1).
+ * Alignment steps are always '+' / '-' (src/alignments.cpp:86).
+ */
+#ifndef GFALIGN_SCORER_H
+#define GFALIGN_SCORER_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GFAL_ABI_VERSION 1
+
+/* include/alignments.h:246 (MAX_N 1001): longest path / alignment accepted. */
+#define GFAL_MAX_STEPS 1000
+
+#define GFAL_STEP_OTHER 0x40000000
+
+#define GFAL_OK            0
+#define GFAL_E_ARG        -1  /* null pointer, negative size, bad offsets      */
+#define GFAL_E_RANGE      -2  /* a path or alignment outside 1..GFAL_MAX_STEPS
+                                 steps (UB in the reference), or a node id
+                                 outside [0, n_nodes)                          */
+#define GFAL_E_NO_DEVICE  -3  /* no HIP device / device index out of range     */
+#define GFAL_E_HIP        -4  /* a HIP runtime call failed (see gfal_last_error)*/
+#define GFAL_E_NOMEM      -5
+
+typedef struct gfal_scorer gfal_scorer;
+
+/* What src/eval.cpp:63-65 PathAlignmentStats holds, one per candidate path. */
+typedef struct {
+    uint32_t bad, good, unaligned;
+} gfal_stats;
+
+int         gfal_abi_version(void);
+const char *gfal_strerror(int code);
+/* Text of the last failure on this thread (HIP error string and call site). */
+const char *gfal_last_error(void);
+/* Number of HIP devices visible, or a negative GFAL_E_* code. */
+int         gfal_device_count(void);
+
+/*
+ * Upload one shard of alignments (what src/eval.cpp:123 getPaths() yields,
+ * done once per search) to `device` and lay it out for the kernels.
+ *   aln_off   [n_aln + 1]  CSR offsets into aln_steps, aln_off[0] == 0
+ *   aln_steps [aln_off[n_aln]] packed steps
+ *   n_nodes   size of the node-id space (reference uId range)
+ * Host buffers are only read during the call.  An empty shard (n_aln == 0) is
+ * valid.  An alignment with zero steps is valid and scores "good" for every
+ * path (src/alignments.cpp:516-524 with m == 0).
+ */
+int gfal_scorer_create(const int32_t *aln_off, const int32_t *aln_steps,
+                       int64_t n_aln, int32_t n_nodes, int device,
+                       gfal_scorer **out);
+
+void gfal_scorer_destroy(gfal_scorer *s);
+
+/*
+ * evaluatePath for a batch of candidate paths (src/eval.cpp:67-108 once per
+ * path).  Blocking; host buffers in, host counters out.
+ *   path_off   [n_paths + 1], path_steps packed (GFAL_STEP_OTHER allowed)
+ *   filter     src/eval.cpp:81-91 (true in search, false in evalPath)
+ *   bad, good  [n_paths] required;  unaligned [n_paths] nullable
+ */
+int gfal_scorer_score(gfal_scorer *s,
+                      const int32_t *path_off, const int32_t *path_steps,
+                      int32_t n_paths, int filter,
+                      uint32_t *bad, uint32_t *good, uint32_t *unaligned);
+
+/*
+ * Same work with everything resident in device memory and no host
+ * synchronisation: the form bench.py and the multi-GPU path use (the counters
+ * stay on the device for the RCCL all-reduce).  Enqueued on `hip_stream`
+ * (a hipStream_t; NULL = the default stream).
+ *   d_path_off   device int32 [n_paths + 1]
+ *   d_path_steps device int32 [total_steps]   (total_steps == path_off[n_paths])
+ *   max_path_len upper bound of any path length (<= GFAL_MAX_STEPS)
+ *   d_counts     device uint32 [3 * n_paths]: bad[P] | good[P] | unaligned[P];
+ *                overwritten, not accumulated
+ * Lengths/ids are validated on the device; a violation is reported by
+ * gfal_scorer_sync_status() after the stream has been synchronised and leaves
+ * d_counts unspecified.
+ */
+int gfal_scorer_score_device(gfal_scorer *s,
+                             const int32_t *d_path_off, const int32_t *d_path_steps,
+                             int32_t n_paths, int64_t total_steps,
+                             int32_t max_path_len, int filter,
+                             uint32_t *d_counts, void *hip_stream);
+
+/* Status word of the most recent score_device call (blocks on its stream). */
+int gfal_scorer_sync_status(gfal_scorer *s);
+
+/*
+ * Traceback scores of ONE path against every alignment of the shard, both
+ * orientations (src/eval.cpp:92-93): what evalPath prints per alignment
+ * (src/eval.cpp:100-102).  fw, rc: host int32 [n_aln], in the order the
+ * alignments were given to gfal_scorer_create.
+ */
+int gfal_scorer_pair_scores(gfal_scorer *s, const int32_t *path_steps, int32_t n,
+                            int32_t *fw, int32_t *rc);
+
+/* ---- introspection used by bench.py / tests; no effect on results ---- */
+
+typedef struct {
+    int64_t  n_aln;          /* alignments in the shard                        */
+    int64_t  n_steps;        /* their total step count S                       */
+    int32_t  n_nodes;        /* node-id space given at create                  */
+    int32_t  n_local_nodes;  /* distinct nodes that occur in the shard         */
+    int32_t  max_aln_len;
+    int32_t  tile_paths;     /* candidate paths staged per workgroup (last run)*/
+    int32_t  n_workgroups;   /* grid of the scan kernel (last run)             */
+    int32_t  lds_bytes;      /* dynamic LDS per workgroup (last run)           */
+    int64_t  dp_pairs;       /* pairs sent to the exact-DP kernel (last run,
+                                valid after gfal_scorer_sync_status)           */
+    float    scan_ms;        /* scan kernel, HIP events (profiling on)         */
+    float    dp_ms;          /* exact-DP kernel, HIP events (profiling on)     */
+    float    total_ms;       /* whole score_device call, HIP events            */
+} gfal_info;
+
+/* Record HIP events around the kernels of each score call (off by default). */
+int gfal_scorer_set_profiling(gfal_scorer *s, int enable);
+/* Blocks on the last call's events when profiling is on. */
+int gfal_scorer_get_info(gfal_scorer *s, gfal_info *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

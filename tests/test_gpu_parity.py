@@ -1,0 +1,175 @@
+"""GPU: the HIP path, called through the C ABI, against the CPU oracle
+(bit-exact integer counters) and the committed golden vectors."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+import oracle
+from gfalign_amd import scorer, synth
+from gfalign_amd.scorer import GFAL_STEP_OTHER, Scorer
+from helpers import (GOLDEN, csr, load_appendix_c, parse_path_string,
+                     random3_alignments, random_case, walk_case)
+
+pytestmark = pytest.mark.gpu
+
+
+def check(alns, paths, n_nodes, filters=(True, False)):
+    aoff, ast = csr(alns)
+    poff, pst = csr(paths)
+    with Scorer(aoff, ast, n_nodes) as sc:
+        for flt in filters:
+            bad, good, una = sc.evaluate_paths(poff, pst, flt)
+            ebad, egood, euna = oracle.evaluate_paths(aoff, ast, poff, pst, flt)
+            assert np.array_equal(bad, ebad), ("bad", flt)
+            assert np.array_equal(good, egood), ("good", flt)
+            assert np.array_equal(una, euna), ("unaligned", flt)
+
+
+def test_library_is_the_in_tree_hip_build(gpu):
+    assert os.path.samefile(os.path.dirname(scorer.library_path()),
+                            os.path.join(os.path.dirname(scorer.__file__), "csrc"))
+    assert scorer.device_count() >= 1
+
+
+def test_random3_appendix_c(gpu):
+    ids, _, alns = random3_alignments()
+    aoff, ast = csr(alns)
+    gold = load_appendix_c()
+    paths = [parse_path_string(g["path"], ids) for g in gold["evaluate_path_filter"]]
+    poff, pst = csr(paths)
+    with Scorer(aoff, ast, 5) as sc:
+        bad, good, _ = sc.evaluate_paths(poff, pst, True)
+        assert bad.tolist() == [g["bad"] for g in gold["evaluate_path_filter"]]
+        assert good.tolist() == [g["good"] for g in gold["evaluate_path_filter"]]
+        ep = gold["eval_path"]
+        path = parse_path_string(ep["path"], ids)
+        fw, rc = sc.pair_scores(path)
+        assert np.maximum(fw, rc).tolist() == ep["best_scores"]
+        bad, good, una = sc.evaluate_paths([0, len(path)], path, False)
+        assert (bad[0], good[0], una[0]) == (ep["bad"], ep["good"], 0)
+
+
+def test_committed_kernel_cases(gpu):
+    with open(os.path.join(GOLDEN, "kernel_cases.json")) as f:
+        cases = json.load(f)
+    for c in cases:
+        with Scorer(c["aln_off"], c["aln_steps"], c["n_nodes"]) as sc:
+            for key, flt in (("filter", True), ("nofilter", False)):
+                bad, good, una = sc.evaluate_paths(c["path_off"], c["path_steps"], flt)
+                assert bad.tolist() == c[key]["bad"], (c["name"], key)
+                assert good.tolist() == c[key]["good"], (c["name"], key)
+                assert una.tolist() == c[key]["unaligned"], (c["name"], key)
+            p0 = c["path_steps"][c["path_off"][0]:c["path_off"][1]]
+            fw, rc = sc.pair_scores(p0)
+            assert fw.tolist() == c["pair_scores_path0"]["fw"], c["name"]
+            assert rc.tolist() == c["pair_scores_path0"]["rc"], c["name"]
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_fuzz_tiny_alphabets(gpu, seed):
+    """Few nodes -> many repeats, start-overhangs and traceback ties: the
+    exact-DP kernel decides a large share of the pairs."""
+    rnd = random.Random(seed)
+    alns, paths = random_case(rnd, rnd.randint(1, 4), 3000, 150, 8, 12)
+    check(alns, paths, 8)
+
+
+@pytest.mark.parametrize("seed", [4, 5])
+def test_fuzz_walks(gpu, seed):
+    rnd = random.Random(seed)
+    alns, paths = walk_case(rnd, 25, 120, 4000, 120, 14)
+    check(alns, paths, 32)
+
+
+def test_long_alignments_take_the_generic_path(gpu):
+    """Alignments longer than the 16 register-resident steps."""
+    rnd = random.Random(6)
+    alns, paths = walk_case(rnd, 40, 300, 1500, 40, 60)
+    assert max(len(a) for a in alns) > 16
+    check(alns, paths, 64)
+
+
+def test_maximum_sizes(gpu):
+    """n = m = 1000 (reference MAX_N - 1), repeats included."""
+    rnd = random.Random(7)
+    walk = [(rnd.randrange(300) << 1) | rnd.randrange(2) for _ in range(1000)]
+    alns = [walk, [s ^ 1 for s in reversed(walk)], walk[1:], walk[:999],
+            walk[:500] + [walk[500] ^ 1] + walk[501:], [walk[-1]] + walk[:-1]]
+    alns += [walk[s:s + rnd.randint(1, 30)] for s in
+             (rnd.randrange(0, 970) for _ in range(300))]
+    paths = [walk, walk[:999], walk[1:], walk[:2]]
+    check(alns, paths, 300)
+
+
+def test_edge_cases(gpu):
+    # zero-step alignments, single steps, a node nobody aligns to, m > n
+    alns = [[], [0], [1], [2, 4], [], [4, 2], [6, 6, 6], [0, 2, 4, 6, 8, 10]]
+    paths = [[0], [1], [0, 2, 4], [2, 4], [20, 22], [6, 6], [4, 2, 0]]
+    check(alns, paths, 16)
+    # empty shard
+    with Scorer([0], [], 4) as sc:
+        bad, good, una = sc.evaluate_paths([0, 2], [0, 2], True)
+        assert (bad[0], good[0], una[0]) == (0, 0, 0)
+    # only zero-step alignments
+    check([[], [], []], [[0, 2]], 4)
+
+
+def test_other_orientation_steps(gpu):
+    """A path step whose orientation is neither + nor - (evalPath can produce
+    one): equals no alignment step, still counts for the filter."""
+    O = GFAL_STEP_OTHER
+    alns = [[0], [1], [0, 2], [2, 0], [3, 1], [4], [0, 2, 4]]
+    paths = [[O | 0, 2], [0, O | 2, 4], [O | 0], [O | 4, 2, 0], [0, 2, O | 4]]
+    check(alns, paths, 8)
+
+
+def test_argument_errors(gpu):
+    with Scorer([0, 2], [0, 2], 4) as sc:
+        with pytest.raises(scorer.ScorerError) as e:
+            sc.evaluate_paths([0, 1001], [0] * 1001, True)
+        assert e.value.code == -2
+        with pytest.raises(scorer.ScorerError) as e:
+            sc.evaluate_paths([0, 0], [], True)          # empty path
+        assert e.value.code == -2
+        with pytest.raises(scorer.ScorerError) as e:
+            sc.evaluate_paths([0, 1], [99 << 1], True)   # node id out of range
+        assert e.value.code == -2
+    with pytest.raises(scorer.ScorerError) as e:
+        Scorer([0, 1001], [0] * 1001, 4)
+    assert e.value.code == -2
+    with pytest.raises(scorer.ScorerError) as e:
+        Scorer([0, 1], [8 << 1], 4)
+    assert e.value.code == -2
+
+
+def test_smoke_config_all_paths(gpu):
+    t = synth.make("smoke")
+    aoff, ast, poff, pst = t.aln_off, t.aln_steps, t.path_off, t.path_steps
+    with Scorer(aoff, ast, t.V) as sc:
+        for flt in (True, False):
+            got = sc.evaluate_paths(poff, pst, flt)
+            exp = oracle.evaluate_paths(aoff, ast, poff, pst, flt)
+            for g, e in zip(got, exp):
+                assert np.array_equal(g, e)
+
+
+def test_config2_sample_against_oracle(gpu):
+    """BASELINE config 2 (500 nodes, 100 k alignments): 24 of the 1000
+    candidates, spread over the length range, checked pair-exactly."""
+    t = synth.make("config2")
+    order = np.argsort(np.diff(t.path_off), kind="stable")
+    pick = order[np.linspace(0, t.P - 1, 24).astype(int)]
+    paths = [t.path_steps[t.path_off[k]:t.path_off[k + 1]] for k in pick]
+    poff, pst = csr(paths)
+    with Scorer(t.aln_off, t.aln_steps, t.V) as sc:
+        bad, good, una = sc.evaluate_paths(t.path_off, t.path_steps, True)
+        ebad, egood, euna = oracle.evaluate_paths(t.aln_off, t.aln_steps, poff, pst, True)
+        assert np.array_equal(bad[pick], ebad)
+        assert np.array_equal(good[pick], egood)
+        assert np.array_equal(una[pick], euna)
+        # batch composition must not matter
+        b2, g2, u2 = sc.evaluate_paths(poff, pst, True)
+        assert np.array_equal(b2, ebad) and np.array_equal(g2, egood) and np.array_equal(u2, euna)

@@ -1,0 +1,98 @@
+"""GPU: size-independent properties at BASELINE's full sizes (config 3:
+2 k nodes, 1 M alignments, 10 k candidates), where the oracle is too slow to
+run over everything."""
+import numpy as np
+import pytest
+
+import oracle
+from gfalign_amd import synth
+from gfalign_amd.scorer import Scorer
+from helpers import csr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tangle():
+    return synth.make("config3")
+
+
+@pytest.fixture(scope="module")
+def full(gpu, tangle):
+    t = tangle
+    with Scorer(t.aln_off, t.aln_steps, t.V) as sc:
+        yield sc, sc.evaluate_paths(t.path_off, t.path_steps, True)
+
+
+def test_counts_are_bounded_and_reproducible(full, tangle):
+    sc, (bad, good, una) = full
+    t = tangle
+    assert np.all(bad.astype(np.int64) + good <= t.N)
+    again = sc.evaluate_paths(t.path_off, t.path_steps, True)
+    for a, b in zip((bad, good, una), again):
+        assert np.array_equal(a, b)
+
+
+def test_unaligned_matches_a_histogram(full, tangle):
+    """unaligned(path) = alignment steps whose node is not on the path."""
+    _, (_, _, una) = full
+    t = tangle
+    hist = np.bincount(t.aln_steps >> 1, minlength=t.V)
+    for k in (0, 17, 4242, t.P - 1):
+        nodes = np.unique(t.path_steps[t.path_off[k]:t.path_off[k + 1]] >> 1)
+        assert una[k] == t.S - hist[nodes].sum()
+
+
+def test_shards_add_up(full, tangle):
+    """The multi-GPU contract: counters of disjoint alignment shards sum to the
+    counters of the whole set (src/eval.cpp:80-106 is a sum over alignments)."""
+    _, (bad, good, una) = full
+    t = tangle
+    cut = t.N // 3
+    acc = [np.zeros(t.P, np.uint64) for _ in range(3)]
+    for lo, hi in ((0, cut), (cut, t.N)):
+        off = (t.aln_off[lo:hi + 1] - t.aln_off[lo]).astype(np.int32)
+        st = t.aln_steps[t.aln_off[lo]:t.aln_off[hi]]
+        with Scorer(off, st, t.V) as sc:
+            for a, part in zip(acc, sc.evaluate_paths(t.path_off, t.path_steps, True)):
+                a += part
+    assert np.array_equal(acc[0], bad) and np.array_equal(acc[1], good)
+    assert np.array_equal(acc[2], una)
+
+
+def test_truth_walk_explains_every_clean_alignment(full, tangle):
+    """Scoring the whole truth walk: every alignment that is an exact sub-walk
+    (either strand) is good; counted here independently with numpy."""
+    sc, _ = full
+    t = tangle
+    T = t.T
+    bad, good, _ = sc.evaluate_paths([0, len(T)], T, True)
+    # independent count: windows of T (and of rc(T)) as byte strings
+    Trc = (T[::-1] ^ 1).astype(np.int32)
+    m = np.diff(t.aln_off)
+    exp_good = 0
+    for L in np.unique(m):
+        win = {T[s:s + L].tobytes() for s in range(len(T) - L + 1)}
+        win |= {Trc[s:s + L].tobytes() for s in range(len(T) - L + 1)}
+        idx = np.flatnonzero(m == L)
+        rows = t.aln_steps[(t.aln_off[idx][:, None] + np.arange(L)[None, :])]
+        exp_good += sum(r.tobytes() in win for r in rows)
+    # start-overhangs can add a few more goods, never fewer
+    assert good[0] >= exp_good
+    assert good[0] - exp_good <= 0.01 * t.N
+    assert bad[0] + good[0] <= t.N
+
+
+def test_sample_of_full_batch_is_pair_exact(full, tangle):
+    """12 of the 10 k candidates against a 60 k-alignment slice, oracle-exact."""
+    t = tangle
+    pick = np.linspace(0, t.P - 1, 12).astype(int)
+    paths = [t.path_steps[t.path_off[k]:t.path_off[k + 1]] for k in pick]
+    poff, pst = csr(paths)
+    hi = 60_000
+    off, st = t.aln_off[:hi + 1], t.aln_steps[:t.aln_off[hi]]
+    with Scorer(off, st, t.V) as sc:
+        got = sc.evaluate_paths(poff, pst, True)
+    exp = oracle.evaluate_paths(off, st, poff, pst, True)
+    for g, e in zip(got, exp):
+        assert np.array_equal(g, e)
