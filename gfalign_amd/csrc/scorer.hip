@@ -561,20 +561,6 @@ __device__ int traceback_score(const StepsA &A, const StepsB &B, uint32_t *row,
     return cell_dp(c) - cell_x(c);
 }
 
-// Does some proper suffix of B equal a prefix of A?  (Precondition of a free
-// traceback when B is not a subpath of A and m <= n.)
-__device__ bool has_overhang(const StepsA &A, const StepsB &B)
-{
-    const int m = B.m;
-    for (int len = 1; len <= m - 1 && len <= A.n; ++len) {
-        bool eq = true;
-        for (int k = 0; eq && k < len; ++k)
-            eq = (uint32_t)A.step[k] == B.at(m - len + k);
-        if (eq) return true;
-    }
-    return false;
-}
-
 __global__ __launch_bounds__(DP_THREADS) void k_dp(
     Items items, const uint16_t *__restrict__ images, ImageLayout L, int n_paths,
     const unsigned long long *__restrict__ worklist,
@@ -594,11 +580,13 @@ __global__ __launch_bounds__(DP_THREADS) void k_dp(
         StepsA A{img + L.step_at(), (int)img[L.len_at()]};
         StepsB B{items.steps + (size_t)items.base[it] * WAVE + ln,
                  (int)items.len[it], 0u};
-        bool good = false;
-        for (uint32_t flip = 0; flip < 2 && !good; ++flip) {
-            B.flip = flip;
-            if (has_overhang(A, B)) good = traceback_score(A, B, row, stride) == 0;
-        }
+        // src/eval.cpp:92-98: good iff either orientation tracebacks for free.
+        // Both fills always run (no per-lane early exit: the lanes of a wave
+        // stay in step through the row loops).
+        const int fw = traceback_score(A, B, row, stride);
+        B.flip = 1u;
+        const int rc = traceback_score(A, B, row, stride);
+        const bool good = fw == 0 || rc == 0;
         atomicAdd(&counts[(good ? n_paths : 0) + p], 1u);
     }
 }
