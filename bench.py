@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""Benchmark of the path-scoring hot path (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload config3]
+
+One "step" = one pass of the hot path over one batch: every candidate path of
+the workload scored against every alignment (reference src/eval.cpp:67-108 once
+per candidate), with alignments, candidates and counters resident in HBM when
+the timed region starts.  N > 1 (launched by torch.distributed.run, one rank
+per GPU): the alignments are sharded over the ranks, every rank scores the whole
+batch against its shard, and the per-path counters are summed with one RCCL
+all-reduce inside the step -- the same total work for every N ("strong").
+
+Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for how `roofline`
+and `cpu_baseline` are defined.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def cpu_baseline(t, budget_pairs=1.6e6):
+    """Time the CPU oracle (port of the reference algorithm) on a bounded
+    sample of the SAME workload: 8 candidates spread over the length range
+    against the first alignments, sized for roughly 10-30 s on one core."""
+    import oracle
+    n_paths = 8
+    n_aln = int(min(t.N, budget_pairs // n_paths))
+    order = np.argsort(np.diff(t.path_off), kind="stable")
+    pick = order[np.linspace(0, t.P - 1, n_paths).astype(int)]
+    paths = [t.path_steps[t.path_off[k]:t.path_off[k + 1]] for k in pick]
+    poff = np.zeros(n_paths + 1, np.int32)
+    poff[1:] = np.cumsum([len(p) for p in paths])
+    pst = np.concatenate(paths).astype(np.int32)
+    aoff = t.aln_off[:n_aln + 1]
+    ast = t.aln_steps[:aoff[-1]]
+    oracle.lib()
+    t0 = time.perf_counter()
+    bad, good, una = oracle.evaluate_paths(aoff, ast, poff, pst, True)
+    dt = time.perf_counter() - t0
+    pairs_per_s = n_paths * n_aln / dt
+    return {
+        "value": pairs_per_s / t.N,           # candidate paths / s on the full N
+        "unit": "paths/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": "%d candidates (length quantiles) x first %d alignments of %s, "
+                  "%.1f s on 1 core, scaled to N=%d; oracle/gfalign_oracle.c "
+                  "(full NW + traceback, fw+rc, filter on)" % (n_paths, n_aln, t.name, dt, t.N),
+    }, (pick, n_aln, bad, good, una)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="config3")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from gfalign_amd import shard, synth
+    from gfalign_amd.scorer import Scorer
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run "
+                     "(one rank per GPU)" % args.gpus)
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X (no CPU fallback on the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    t = synth.make(args.workload)
+    t.name = args.workload
+    aoff, ast = shard.take_shard(t.aln_off, t.aln_steps, rank, world)
+    sc = Scorer(aoff, ast, t.V, device=local_rank)
+
+    P = t.P
+    total_steps = int(t.path_off[-1])
+    max_len = int(np.diff(t.path_off).max())
+    d_off = torch.from_numpy(t.path_off.astype(np.int32)).to(dev)
+    d_steps = torch.from_numpy(t.path_steps.astype(np.int32)).to(dev)
+    d_counts = torch.zeros(3 * P, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream(dev)
+
+    def step():
+        sc.score_device(d_off.data_ptr(), d_steps.data_ptr(), P, total_steps, max_len,
+                        True, d_counts.data_ptr(), stream.cuda_stream)
+        shard.all_reduce_counts(d_counts)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    sc.sync_status()
+
+    sc.set_profiling(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    sc.sync_status()
+    info = sc.info()
+    sc.set_profiling(False)
+
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+
+    counts = d_counts.cpu().numpy().view(np.uint32)
+    bad, good, una = counts[:P], counts[P:2 * P], counts[2 * P:]
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = P * args.steps / elapsed
+        # dominant kernel: k_scan.  Algorithmic bytes of one launch on this rank
+        # (SURVEY.md 8(d)): sum over candidates of 4 S + 4 (N+1) + 4 n + 12 with
+        # this rank's S and N.
+        S_r, N_r = int(aoff[-1]), len(aoff) - 1
+        alg_bytes = P * (4 * S_r + 4 * (N_r + 1) + 12) + 4 * total_steps
+        scan_s = info["scan_ms"] * 1e-3
+        achieved = alg_bytes / scan_s / 1e9 if scan_s > 0 else None
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
+        if world == 1 and os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f).get("hbm_bytes_per_launch")
+        out = {
+            "metric": "candidate paths scored/sec in search mode",
+            "value": value,
+            "unit": "paths/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "int32",
+            "data": "synthetic",
+            "config": {
+                "workload": "%s: synthetic %d-node tangle, %d GAF alignments (S=%d steps), "
+                            "%d candidate paths, filter on" % (args.workload, t.V, t.N, t.S, P),
+                "parallelism": "alignments sharded over %d GPU(s), all-reduce of int32[3P]" % world,
+                "tile_paths": info["tile_paths"],
+                "workgroups": info["n_workgroups"],
+                "dp_pairs_per_step": info["dp_pairs"],
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_scan",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+                "traffic": traffic,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "kernel_ms": info["scan_ms"],
+                "dp_kernel_ms": info["dp_ms"],
+                "call_ms": info["total_ms"],
+                "note": "algorithmic bytes re-read the whole alignment set per candidate; "
+                        "k_scan reuses each alignment load for tile_paths candidates from "
+                        "LDS, so achieved may exceed the HBM peak (DESIGN.md)",
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            base, (pick, n_aln, ebad, egood, euna) = cpu_baseline(t)
+            out["cpu_baseline"] = base
+            # the same sample doubles as an end-of-run parity check
+            with Scorer(t.aln_off[:n_aln + 1], t.aln_steps[:t.aln_off[n_aln]], t.V,
+                        device=local_rank) as chk:
+                paths = [t.path_steps[t.path_off[k]:t.path_off[k + 1]] for k in pick]
+                poff = np.zeros(len(paths) + 1, np.int32)
+                poff[1:] = np.cumsum([len(p) for p in paths])
+                gb, gg, gu = chk.evaluate_paths(poff, np.concatenate(paths), True)
+            if not (np.array_equal(gb, ebad) and np.array_equal(gg, egood)
+                    and np.array_equal(gu, euna)):
+                sys.exit("PARITY FAILURE: HIP counters differ from the oracle on the sample")
+            out["config"]["parity_sample"] = "bit-exact vs oracle on the cpu_baseline sample"
+        print(json.dumps(out))
+    sc.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -246,11 +246,25 @@ __device__ __forceinline__ void push_pairs(const ScanArgs &a, bool want, int lan
     }
 }
 
+// live lanes: does B[start + dirn*k] ^ flipbit equal path step k for k in
+// [1, len)?  (k = 0 was checked by the caller.)  len, start, dirn are
+// wave-uniform; B is re-read from the item (coalesced, cache-hot).
+__device__ __forceinline__ bool tail_equals(const uint16_t *__restrict__ bp, int start,
+                                            int dirn, int len, uint32_t flipbit,
+                                            const uint16_t *step, bool live)
+{
+    bool eq = live;
+    for (int k = 1; k < len; ++k)
+        eq &= ((uint32_t)bp[(start + dirn * k) * WAVE] ^ flipbit) == (uint32_t)step[k];
+    return eq;
+}
+
 // One item (64 alignments of length M, steps in b[]) against one staged path.
 // Returns through good/bad whether this lane's alignment was decided here.
 template <int M>
 __device__ __forceinline__ void eval_item(const ScanArgs &a, const PathView &pv,
-                                          const uint32_t (&b)[M], bool valid,
+                                          const uint32_t (&b)[M],
+                                          const uint16_t *__restrict__ bp, bool valid,
                                           int lane, uint32_t path_global,
                                           uint32_t slot, bool &good, bool &bad)
 {
@@ -298,14 +312,21 @@ __device__ __forceinline__ void eval_item(const ScanArgs &a, const PathView &pv,
         good |= open;
         return;
     }
-    // Only a suffix of B (or of rc(B)) equal to a prefix of the path can still
-    // make the traceback free; that needs the path's first step inside B.
+    // B is not a subpath and m <= n: the traceback can only stay free if a
+    // proper suffix of B (or of rc(B)) equals a prefix of the path
+    // ("start-overhang").  Exact test here; the few pairs that pass
+    // it are decided by the DP kernel.
     bool cand = false;
 #pragma unroll
-    for (int t = 1; t < M; ++t) cand |= b[t] == pv.a0;
+    for (int t = 1; t < M; ++t) {            // B[t..M) == path[0..M-t) ?
+        const bool live = open && b[t] == pv.a0;
+        if (__any(live)) cand |= tail_equals(bp, t, 1, M - t, 0u, pv.step, live);
+    }
 #pragma unroll
-    for (int t = 0; t < M - 1; ++t) cand |= (b[t] ^ 1u) == pv.a0;
-    cand &= open;
+    for (int t = 0; t < M - 1; ++t) {        // rc(B)[M-1-t..M) == path[0..t+1) ?
+        const bool live = open && (b[t] ^ 1u) == pv.a0;
+        if (__any(live)) cand |= tail_equals(bp, t, -1, t + 1, 1u, pv.step, live);
+    }
     bad = open && !cand;
     push_pairs(a, cand, lane, path_global, slot);
 }
@@ -355,11 +376,12 @@ __device__ __noinline__ void eval_item_long(const ScanArgs &a, const PathView &p
         return;
     }
     bool cand = false;
-    if (open) {
-        for (int t = 0; t < M; ++t) {
-            uint32_t bt = bp[t * WAVE];
-            cand |= (t >= 1 && bt == pv.a0) || (t < M - 1 && (bt ^ 1u) == pv.a0);
-        }
+    for (int t = 0; t < M; ++t) {
+        const uint32_t bt = bp[t * WAVE];
+        const bool live_fw = open && t >= 1 && bt == pv.a0;
+        if (__any(live_fw)) cand |= tail_equals(bp, t, 1, M - t, 0u, pv.step, live_fw);
+        const bool live_rc = open && t < M - 1 && (bt ^ 1u) == pv.a0;
+        if (__any(live_rc)) cand |= tail_equals(bp, t, -1, t + 1, 1u, pv.step, live_rc);
     }
     bad = open && !cand;
     push_pairs(a, cand, lane, path_global, slot);
@@ -389,7 +411,7 @@ __device__ __forceinline__ void scan_item(const ScanArgs &a, const uint16_t *lds
         pv.n = __builtin_amdgcn_readfirstlane((int)img[a.L.len_at()]);
         pv.a0 = __builtin_amdgcn_readfirstlane((uint32_t)pv.step[0]);
         bool good, bad;
-        eval_item<M>(a, pv, b, valid, lane, (uint32_t)(path0 + p), slot, good, bad);
+        eval_item<M>(a, pv, b, bp, valid, lane, (uint32_t)(path0 + p), slot, good, bad);
         uint32_t g = (uint32_t)__popcll(__ballot(good));
         uint32_t d = (uint32_t)__popcll(__ballot(bad));
         if (lane == p) {
@@ -524,8 +546,8 @@ __device__ __forceinline__ uint32_t pack_cell(int dp, int x)
 __device__ __forceinline__ int cell_dp(uint32_t c) { return (int)(int16_t)(c & 0xFFFFu); }
 __device__ __forceinline__ int cell_x(uint32_t c) { return (int)(int16_t)(c >> 16); }
 
-__device__ int traceback_score(const StepsA &A, const StepsB &B, uint32_t *row,
-                               int stride)
+__device__ __forceinline__ int traceback_score(const StepsA &A, const StepsB &B,
+                                               uint32_t *row, int stride)
 {
     const int n = A.n, m = B.m;
     for (int j = 0; j <= m; ++j) {
@@ -561,17 +583,33 @@ __device__ int traceback_score(const StepsA &A, const StepsB &B, uint32_t *row,
     return cell_dp(c) - cell_x(c);
 }
 
+// Row state: one word per column per thread.  Short alignments keep it in LDS
+// ([column][thread], conflict-free); long ones use the HBM scratch.
+template <bool ROWS_IN_LDS>
+__device__ __forceinline__ uint32_t *dp_row(uint32_t *row_scratch, int &stride)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t dp_lds[];
+    if (ROWS_IN_LDS) {
+        stride = DP_THREADS;
+        return dp_lds + threadIdx.x;
+    }
+    stride = gridDim.x * DP_THREADS;
+    return row_scratch + blockIdx.x * DP_THREADS + threadIdx.x;
+}
+
+template <bool ROWS_IN_LDS>
 __global__ __launch_bounds__(DP_THREADS) void k_dp(
     Items items, const uint16_t *__restrict__ images, ImageLayout L, int n_paths,
     const unsigned long long *__restrict__ worklist,
     const uint32_t *__restrict__ wl_count, uint32_t wl_capacity,
     uint32_t *__restrict__ row_scratch, uint32_t *__restrict__ counts)
 {
-    const int stride = gridDim.x * DP_THREADS;
-    const int gtid = blockIdx.x * DP_THREADS + threadIdx.x;
-    uint32_t *row = row_scratch + gtid;
+    int stride;
+    uint32_t *row = dp_row<ROWS_IN_LDS>(row_scratch, stride);
+    const uint32_t n_threads = gridDim.x * DP_THREADS;
+    const uint32_t gtid = blockIdx.x * DP_THREADS + threadIdx.x;
     const uint32_t total = min(*wl_count, wl_capacity);
-    for (uint32_t w = gtid; w < total; w += stride) {
+    for (uint32_t w = gtid; w < total; w += n_threads) {
         const unsigned long long ent = worklist[w];
         const uint32_t p = (uint32_t)(ent >> 32);
         const uint32_t slot = (uint32_t)ent;
@@ -591,18 +629,20 @@ __global__ __launch_bounds__(DP_THREADS) void k_dp(
     }
 }
 
+template <bool ROWS_IN_LDS>
 __global__ __launch_bounds__(DP_THREADS) void k_pairs(
     Items items, const int32_t *__restrict__ slot_orig,
     const uint16_t *__restrict__ image, ImageLayout L,
     uint32_t *__restrict__ row_scratch, int32_t *__restrict__ fw,
     int32_t *__restrict__ rc)
 {
-    const int stride = gridDim.x * DP_THREADS;
-    const int gtid = blockIdx.x * DP_THREADS + threadIdx.x;
-    uint32_t *row = row_scratch + gtid;
+    int stride;
+    uint32_t *row = dp_row<ROWS_IN_LDS>(row_scratch, stride);
+    const long long n_threads = (long long)gridDim.x * DP_THREADS;
+    const long long gtid = (long long)blockIdx.x * DP_THREADS + threadIdx.x;
     const long long n_slots = (long long)items.n_items * WAVE;
     StepsA A{image + L.step_at(), (int)image[L.len_at()]};
-    for (long long s = gtid; s < n_slots; s += stride) {
+    for (long long s = gtid; s < n_slots; s += n_threads) {
         const int32_t orig = slot_orig[s];
         if (orig < 0) continue;
         const uint32_t it = (uint32_t)(s >> 6), ln = (uint32_t)(s & 63);
@@ -657,9 +697,12 @@ struct gfal_scorer {
     hipStream_t last_stream = nullptr;
     bool have_last = false;
     int last_tile = 0, last_grid = 0, last_lds = 0;
+    // profiling: one {start, prep done, scan done, end} event set per call,
+    // kept in a ring and averaged by gfal_scorer_get_info
+    static constexpr int EV_RING = 128;
     bool profiling = false;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    bool ev_valid = false;
+    hipEvent_t ev[EV_RING][4] = {};
+    int ev_calls = 0;   // calls recorded since profiling was switched on
 };
 
 namespace {
@@ -697,15 +740,24 @@ void free_scorer(gfal_scorer *s)
                     s->d_counts};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
-    for (hipEvent_t e : s->ev)
-        if (e) (void)hipEventDestroy(e);
+    for (auto &set : s->ev)
+        for (hipEvent_t e : set)
+            if (e) (void)hipEventDestroy(e);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
 
-int row_scratch_words(int max_aln_len)
+size_t dp_lds_bytes(int max_aln_len)
 {
-    return (max_aln_len + 1) * DP_BLOCKS * DP_THREADS;
+    return (size_t)(max_aln_len + 1) * DP_THREADS * sizeof(uint32_t);
+}
+
+bool dp_rows_fit_lds(int max_aln_len) { return dp_lds_bytes(max_aln_len) <= 32 * 1024; }
+
+size_t row_scratch_words(int max_aln_len)
+{
+    if (dp_rows_fit_lds(max_aln_len)) return 1;
+    return (size_t)(max_aln_len + 1) * DP_BLOCKS * DP_THREADS;
 }
 
 }  // namespace
@@ -893,7 +945,7 @@ int gfal_scorer_create(const int32_t *aln_off, const int32_t *aln_steps,
                          (size_t)s->wl_capacity * sizeof(unsigned long long)));
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_rows),
                          (size_t)row_scratch_words(max_len) * sizeof(uint32_t)));
-    for (hipEvent_t &e : s->ev) CREATE_TRY(hipEventCreate(&e));
+
 #undef CREATE_TRY
     *out = s;
     return GFAL_OK;
@@ -904,8 +956,14 @@ void gfal_scorer_destroy(gfal_scorer *s) { free_scorer(s); }
 int gfal_scorer_set_profiling(gfal_scorer *s, int enable)
 {
     if (!s) return GFAL_E_ARG;
+    if (enable) {
+        HIP_TRY(hipSetDevice(s->device));
+        for (auto &set : s->ev)
+            for (hipEvent_t &e : set)
+                if (!e) HIP_TRY(hipEventCreate(&e));
+    }
     s->profiling = enable != 0;
-    s->ev_valid = false;
+    s->ev_calls = 0;
     return GFAL_OK;
 }
 
@@ -938,7 +996,8 @@ int gfal_scorer_score_device(gfal_scorer *s, const int32_t *d_path_off,
     }
 
     HIP_TRY(hipMemsetAsync(s->d_status, 0, 2 * sizeof(uint32_t), st));
-    if (s->profiling) HIP_TRY(hipEventRecord(s->ev[0], st));
+    hipEvent_t *ev = s->ev[s->ev_calls % gfal_scorer::EV_RING];
+    if (s->profiling) HIP_TRY(hipEventRecord(ev[0], st));
 
     const size_t prep_lds = img_bytes + (size_t)L.nm * sizeof(uint16_t);
     hipLaunchKernelGGL(k_prep, dim3((unsigned)n_paths), dim3(WAVE), prep_lds, st,
@@ -947,7 +1006,7 @@ int gfal_scorer_score_device(gfal_scorer *s, const int32_t *d_path_off,
                        s->d_node_hist, (uint32_t)s->n_steps, s->n_empty, filter, L,
                        s->d_images, d_counts, s->d_status);
     HIP_TRY(hipGetLastError());
-    if (s->profiling) HIP_TRY(hipEventRecord(s->ev[1], st));
+    if (s->profiling) HIP_TRY(hipEventRecord(ev[1], st));
 
     s->last_tile = 0;
     s->last_grid = 0;
@@ -985,18 +1044,24 @@ int gfal_scorer_score_device(gfal_scorer *s, const int32_t *d_path_off,
         s->last_tile = tile;
         s->last_grid = (int)grid;
         s->last_lds = (int)lds;
-        if (s->profiling) HIP_TRY(hipEventRecord(s->ev[2], st));
+        if (s->profiling) HIP_TRY(hipEventRecord(ev[2], st));
 
-        hipLaunchKernelGGL(k_dp, dim3(DP_BLOCKS), dim3(DP_THREADS), 0, st, a.items,
-                           s->d_images, L, (int)n_paths, s->d_worklist,
-                           s->d_status + 1, s->wl_capacity, s->d_rows, d_counts);
+        if (dp_rows_fit_lds(s->max_aln_len))
+            hipLaunchKernelGGL(k_dp<true>, dim3(DP_BLOCKS), dim3(DP_THREADS),
+                               dp_lds_bytes(s->max_aln_len), st, a.items, s->d_images, L,
+                               (int)n_paths, s->d_worklist, s->d_status + 1,
+                               s->wl_capacity, s->d_rows, d_counts);
+        else
+            hipLaunchKernelGGL(k_dp<false>, dim3(DP_BLOCKS), dim3(DP_THREADS), 0, st,
+                               a.items, s->d_images, L, (int)n_paths, s->d_worklist,
+                               s->d_status + 1, s->wl_capacity, s->d_rows, d_counts);
         HIP_TRY(hipGetLastError());
     } else if (s->profiling) {
-        HIP_TRY(hipEventRecord(s->ev[2], st));
+        HIP_TRY(hipEventRecord(ev[2], st));
     }
     if (s->profiling) {
-        HIP_TRY(hipEventRecord(s->ev[3], st));
-        s->ev_valid = true;
+        HIP_TRY(hipEventRecord(ev[3], st));
+        ++s->ev_calls;
     }
     s->last_stream = st;
     s->have_last = true;
@@ -1147,8 +1212,14 @@ int gfal_scorer_pair_scores(gfal_scorer *s, const int32_t *path_steps, int32_t n
                        (long long)s->n_aln, 0);
     if (s->n_items > 0) {
         Items items{s->d_item_steps, s->d_item_base, s->d_item_len, s->n_items};
-        hipLaunchKernelGGL(k_pairs, dim3(DP_BLOCKS), dim3(DP_THREADS), 0, s->stream,
-                           items, s->d_slot_orig, s->d_images, L, s->d_rows, d_fw, d_rc);
+        if (dp_rows_fit_lds(s->max_aln_len))
+            hipLaunchKernelGGL(k_pairs<true>, dim3(DP_BLOCKS), dim3(DP_THREADS),
+                               dp_lds_bytes(s->max_aln_len), s->stream, items,
+                               s->d_slot_orig, s->d_images, L, s->d_rows, d_fw, d_rc);
+        else
+            hipLaunchKernelGGL(k_pairs<false>, dim3(DP_BLOCKS), dim3(DP_THREADS), 0,
+                               s->stream, items, s->d_slot_orig, s->d_images, L,
+                               s->d_rows, d_fw, d_rc);
     }
     hipError_t e3 = hipGetLastError();
     if (e3 == hipSuccess)
@@ -1188,15 +1259,24 @@ int gfal_scorer_get_info(gfal_scorer *s, gfal_info *out)
                                s->last_stream));
         HIP_TRY(hipStreamSynchronize(s->last_stream));
         out->dp_pairs = host[1];
-        if (s->profiling && s->ev_valid) {
-            HIP_TRY(hipEventSynchronize(s->ev[3]));
-            float t = 0.f;
-            HIP_TRY(hipEventElapsedTime(&t, s->ev[1], s->ev[2]));
-            out->scan_ms = t;
-            HIP_TRY(hipEventElapsedTime(&t, s->ev[2], s->ev[3]));
-            out->dp_ms = t;
-            HIP_TRY(hipEventElapsedTime(&t, s->ev[0], s->ev[3]));
-            out->total_ms = t;
+        if (s->profiling && s->ev_calls > 0) {
+            const int n = std::min(s->ev_calls, (int)gfal_scorer::EV_RING);
+            double scan = 0, dp = 0, total = 0;
+            for (int i = 0; i < n; ++i) {
+                hipEvent_t *ev = s->ev[i];
+                float t = 0.f;
+                HIP_TRY(hipEventSynchronize(ev[3]));
+                HIP_TRY(hipEventElapsedTime(&t, ev[1], ev[2]));
+                scan += t;
+                HIP_TRY(hipEventElapsedTime(&t, ev[2], ev[3]));
+                dp += t;
+                HIP_TRY(hipEventElapsedTime(&t, ev[0], ev[3]));
+                total += t;
+            }
+            out->scan_ms = (float)(scan / n);
+            out->dp_ms = (float)(dp / n);
+            out->total_ms = (float)(total / n);
+            out->profiled_calls = n;
         }
     }
     return GFAL_OK;

@@ -25,7 +25,8 @@ class GfalInfo(ctypes.Structure):
                 ("max_aln_len", ctypes.c_int32), ("tile_paths", ctypes.c_int32),
                 ("n_workgroups", ctypes.c_int32), ("lds_bytes", ctypes.c_int32),
                 ("dp_pairs", ctypes.c_int64), ("scan_ms", ctypes.c_float),
-                ("dp_ms", ctypes.c_float), ("total_ms", ctypes.c_float)]
+                ("dp_ms", ctypes.c_float), ("total_ms", ctypes.c_float),
+                ("profiled_calls", ctypes.c_int32)]
 
 
 # every symbol include/gfalign_scorer.h declares

@@ -139,14 +139,16 @@ typedef struct {
     int32_t  lds_bytes;      /* dynamic LDS per workgroup (last run)           */
     int64_t  dp_pairs;       /* pairs sent to the exact-DP kernel (last run,
                                 valid after gfal_scorer_sync_status)           */
-    float    scan_ms;        /* scan kernel, HIP events (profiling on)         */
-    float    dp_ms;          /* exact-DP kernel, HIP events (profiling on)     */
-    float    total_ms;       /* whole score_device call, HIP events            */
+    float    scan_ms;        /* scan kernel, HIP events: mean over the calls   */
+    float    dp_ms;          /* exact-DP kernel             made since         */
+    float    total_ms;       /* whole score_device call     profiling went on  */
+    int32_t  profiled_calls; /* calls in that mean (ring of 128)               */
 } gfal_info;
 
-/* Record HIP events around the kernels of each score call (off by default). */
+/* Record HIP events (on the caller's stream) around the kernels of each score
+   call; switching it on resets the statistics.  Off by default. */
 int gfal_scorer_set_profiling(gfal_scorer *s, int enable);
-/* Blocks on the last call's events when profiling is on. */
+/* Blocks on the recorded events when profiling is on. */
 int gfal_scorer_get_info(gfal_scorer *s, gfal_info *out);
 
 #ifdef __cplusplus
