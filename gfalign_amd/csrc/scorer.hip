@@ -39,7 +39,7 @@ constexpr int WAVE = 64;
 constexpr int SCAN_THREADS = 512;
 constexpr int SCAN_WAVES = SCAN_THREADS / WAVE;
 constexpr int MAX_REG_M = 16;          // alignments up to this length live in VGPRs
-constexpr int MAX_TILE = 64;           // lane p of a wave owns path p's counter
+constexpr int MAX_TILE = 32;           // one bit per tile path in the node masks
 constexpr int LDS_BUDGET = 80 * 1024;  // two workgroups per CU (160 KiB LDS)
 constexpr int DP_THREADS = 64;
 constexpr int DP_BLOCKS = 512;
@@ -75,22 +75,28 @@ void set_err(const char *fmt, ...)
     } while (0)
 
 // Geometry of one path image, in uint16 units.  Shared by host and device.
+//   first[v2]  node -> chain entry of its first occurrence on the path
+//   next[nm]   position -> chain entry of the node's next occurrence
+//   step[nm]   the path's steps (local packed codes)
+//   rstep[nm]  the steps of the path's reverse complement
+//   len, pad
 struct ImageLayout {
     int v2;        // first-occurrence table entries (n_local rounded up to even)
-    int nm;        // capacity of the chain / step arrays (even)
+    int nm;        // capacity of the chain / step arrays (even, >= MAX_REG_M)
     int total;     // whole image, multiple of 8 (16 bytes)
     __host__ __device__ int first_at() const { return 0; }
     __host__ __device__ int next_at() const { return v2; }
     __host__ __device__ int step_at() const { return v2 + nm; }
-    __host__ __device__ int len_at() const { return v2 + 2 * nm; }
+    __host__ __device__ int rstep_at() const { return v2 + 2 * nm; }
+    __host__ __device__ int len_at() const { return v2 + 3 * nm; }
 };
 
 ImageLayout make_layout(int n_local, int max_len)
 {
     ImageLayout L;
     L.v2 = (n_local + 1) & ~1;
-    L.nm = (max_len + 1) & ~1;
-    L.total = (L.v2 + 2 * L.nm + 2 + 7) & ~7;
+    L.nm = std::max((max_len + 1) & ~1, MAX_REG_M);
+    L.total = (L.v2 + 3 * L.nm + 2 + 7) & ~7;
     return L;
 }
 
@@ -135,6 +141,7 @@ __global__ __launch_bounds__(WAVE) void k_prep(
     uint16_t *first = img + L.first_at();
     uint16_t *next = img + L.next_at();
     uint16_t *step = img + L.step_at();
+    uint16_t *rstep = img + L.rstep_at();
     for (int i = lane; i < L.total; i += WAVE) img[i] = (uint16_t)ENT_NONE;
     __syncthreads();
 
@@ -153,6 +160,12 @@ __global__ __launch_bounds__(WAVE) void k_prep(
     }
     if (!id_ok) atomicOr(status, ST_BAD_ID);
     __syncthreads();
+    // reverse complement (include/alignments.h:64-70), so that "rc(B) is a
+    // subpath of the path" is searched as "B is a subpath of rc(path)"
+    for (int i = lane; i < n; i += WAVE) {
+        uint32_t code = step[n - 1 - i];
+        rstep[i] = (uint16_t)(code == STEP_NOMATCH ? STEP_NOMATCH : (code ^ 1u));
+    }
 
     // Occurrence chains in increasing position order: walk the path backwards.
     if (lane == 0) {
@@ -216,10 +229,15 @@ struct ScanArgs {
     uint32_t *status;
 };
 
-struct PathView {
-    const uint16_t *first, *next, *step;
-    int n;
-    uint32_t a0;
+// What a wave keeps about the tile while it walks its items.
+struct TileView {
+    const uint16_t *lds;       // T images
+    const uint32_t *nodemask;  // [v2] bit p: node occurs on tile path p
+    int tile_paths;
+    int path0;
+    uint32_t all_paths;        // low tile_paths bits set
+    int hdr_n;                 // lane p: length of tile path p
+    uint32_t hdr_a0;           // lane p: first step of tile path p
 };
 
 __device__ __forceinline__ uint32_t lanes_below(unsigned long long m, int lane)
@@ -259,137 +277,71 @@ __device__ __forceinline__ bool tail_equals(const uint16_t *__restrict__ bp, int
     return eq;
 }
 
-// One item (64 alignments of length M, steps in b[]) against one staged path.
-// Returns through good/bad whether this lane's alignment was decided here.
+// Occurrence-chain search (DESIGN.md "k_scan"): is B a contiguous subpath of
+// the path, or of its reverse complement?  `e` = chain head for B[0]'s node.
+// Both directions are forward scans: the image holds the path's steps and,
+// behind them, the steps of its reverse complement.
 template <int M>
-__device__ __forceinline__ void eval_item(const ScanArgs &a, const PathView &pv,
-                                          const uint32_t (&b)[M],
-                                          const uint16_t *__restrict__ bp, bool valid,
-                                          int lane, uint32_t path_global,
-                                          uint32_t slot, bool &good, bool &bad)
+__device__ __forceinline__ bool subpath_search(const uint32_t (&b)[M], uint32_t e,
+                                               const uint16_t *next,
+                                               const uint16_t *stepbase, int nm, int n)
 {
-    good = false;
-    bad = false;
+    bool found = false;
     const uint32_t b0 = b[0];
-    uint32_t e0 = valid ? (uint32_t)pv.first[b0 >> 1] : ENT_NONE;
-    // search mode: an alignment whose first node is off the path is filtered
-    // (src/eval.cpp:83-90); if that holds for the whole wave, nothing to do.
-    if (a.filter && !__any(e0 != ENT_NONE)) return;
-
-    bool found = false;
-    uint32_t e = e0;
     while (__any(e != ENT_NONE)) {
         if (e != ENT_NONE) {
-            int pos = (int)(e & ENT_POS);
-            // dir 0: the path step equals b0 -> B may start here going right.
-            // dir 1: it is b0's complement  -> rc(B) may END here (going left).
-            uint32_t dir = (e >> 15) ^ (b0 & 1u);
-            bool fits = !(e & ENT_NOMATCH) &&
-                        (dir ? (pos >= M - 1) : (pos + M <= pv.n));
-            // a lane whose window does not fit re-reads step[0] (in range)
-            int at = fits ? pos : 0;
-            int sgn = fits ? (dir ? -1 : 1) : 0;
+            const int pos = (int)(e & ENT_POS);
+            // dir 0: the path step at pos equals b0 -> B may start here.
+            // dir 1: it is b0's complement -> rc(B) may end here, i.e. B may
+            //        start at n-1-pos of the reverse-complemented path.
+            const uint32_t dir = (e >> 15) ^ (b0 & 1u);
+            const bool fits = !(e & ENT_NOMATCH) &&
+                              (dir ? (pos >= M - 1) : (pos + M <= n));
+            // lanes whose window does not fit re-read stepbase[0..M) (in range)
+            const int at = fits ? (dir ? nm + (n - 1 - pos) : pos) : 0;
+            const uint16_t *w = stepbase + at;
             bool ok = fits;
 #pragma unroll
-            for (int t = 1; t < M; ++t)
-                ok &= (uint32_t)pv.step[at + sgn * t] == (b[t] ^ dir);
+            for (int t = 1; t < M; ++t) ok &= (uint32_t)w[t] == b[t];
             found |= ok;
-            e = found ? ENT_NONE : (uint32_t)pv.next[pos];
+            e = found ? ENT_NONE : (uint32_t)next[pos];
         }
     }
-    good = found;
-    bool open = valid && !found;
-    if (!__any(open)) return;
-
-    if (a.filter) {
-        bool present = e0 != ENT_NONE;
-#pragma unroll
-        for (int t = 1; t < M; ++t)
-            present &= (!open) || pv.first[b[t] >> 1] != ENT_NONE;
-        open &= present;
-    }
-    if (M > pv.n) {                       // src/alignments.cpp:500 row-0 bound
-        good |= open;
-        return;
-    }
-    // B is not a subpath and m <= n: the traceback can only stay free if a
-    // proper suffix of B (or of rc(B)) equals a prefix of the path
-    // ("start-overhang").  Exact test here; the few pairs that pass
-    // it are decided by the DP kernel.
-    bool cand = false;
-#pragma unroll
-    for (int t = 1; t < M; ++t) {            // B[t..M) == path[0..M-t) ?
-        const bool live = open && b[t] == pv.a0;
-        if (__any(live)) cand |= tail_equals(bp, t, 1, M - t, 0u, pv.step, live);
-    }
-#pragma unroll
-    for (int t = 0; t < M - 1; ++t) {        // rc(B)[M-1-t..M) == path[0..t+1) ?
-        const bool live = open && (b[t] ^ 1u) == pv.a0;
-        if (__any(live)) cand |= tail_equals(bp, t, -1, t + 1, 1u, pv.step, live);
-    }
-    bad = open && !cand;
-    push_pairs(a, cand, lane, path_global, slot);
+    return found;
 }
 
-// Same decision for alignments too long for registers: steps re-read from the
-// item (L1/L2 hot, coalesced).
-__device__ __noinline__ void eval_item_long(const ScanArgs &a, const PathView &pv,
-                                            const uint16_t *__restrict__ bp, int M,
-                                            bool valid, int lane,
-                                            uint32_t path_global, uint32_t slot,
-                                            bool &good, bool &bad)
+__device__ __forceinline__ bool subpath_search_long(const uint16_t *__restrict__ bp, int M,
+                                                    uint32_t b0, uint32_t e,
+                                                    const uint16_t *next,
+                                                    const uint16_t *stepbase, int nm,
+                                                    int n)
 {
-    good = false;
-    bad = false;
-    const uint32_t b0 = valid ? (uint32_t)bp[0] : 0u;
-    uint32_t e0 = valid ? (uint32_t)pv.first[b0 >> 1] : ENT_NONE;
-    if (a.filter && !__any(e0 != ENT_NONE)) return;
-
     bool found = false;
-    uint32_t e = e0;
     while (__any(e != ENT_NONE)) {
         if (e != ENT_NONE) {
-            int pos = (int)(e & ENT_POS);
-            uint32_t dir = (e >> 15) ^ (b0 & 1u);
-            bool fits = !(e & ENT_NOMATCH) &&
-                        (dir ? (pos >= M - 1) : (pos + M <= pv.n));
-            int sgn = dir ? -1 : 1;
+            const int pos = (int)(e & ENT_POS);
+            const uint32_t dir = (e >> 15) ^ (b0 & 1u);
+            const bool fits = !(e & ENT_NOMATCH) &&
+                              (dir ? (pos >= M - 1) : (pos + M <= n));
+            const int at = fits ? (dir ? nm + (n - 1 - pos) : pos) : 0;
+            const uint16_t *w = stepbase + at;
             bool ok = fits;
-            for (int t = 1; ok && t < M; ++t)
-                ok = (uint32_t)pv.step[pos + sgn * t] == ((uint32_t)bp[t * WAVE] ^ dir);
+            // wave-uniform trip count; lanes that already failed keep reading
+            // (in range: at + t < at + M) instead of leaving the loop early
+            const int lim = __any(fits) ? M : 1;
+            for (int t = 1; t < lim; ++t)
+                ok &= (!fits) || (uint32_t)w[t] == (uint32_t)bp[t * WAVE];
             found |= ok;
-            e = found ? ENT_NONE : (uint32_t)pv.next[pos];
+            e = found ? ENT_NONE : (uint32_t)next[pos];
         }
     }
-    good = found;
-    bool open = valid && !found;
-    if (!__any(open)) return;
-
-    if (a.filter && open) {
-        bool present = e0 != ENT_NONE;
-        for (int t = 1; present && t < M; ++t)
-            present = pv.first[(uint32_t)bp[t * WAVE] >> 1] != ENT_NONE;
-        open = present;
-    }
-    if (M > pv.n) {
-        good |= open;
-        return;
-    }
-    bool cand = false;
-    for (int t = 0; t < M; ++t) {
-        const uint32_t bt = bp[t * WAVE];
-        const bool live_fw = open && t >= 1 && bt == pv.a0;
-        if (__any(live_fw)) cand |= tail_equals(bp, t, 1, M - t, 0u, pv.step, live_fw);
-        const bool live_rc = open && t < M - 1 && (bt ^ 1u) == pv.a0;
-        if (__any(live_rc)) cand |= tail_equals(bp, t, -1, t + 1, 1u, pv.step, live_rc);
-    }
-    bad = open && !cand;
-    push_pairs(a, cand, lane, path_global, slot);
+    return found;
 }
 
+// One item against the tile.  STEPS_IN_REGS: M is the template constant and
+// b[] holds the steps; otherwise M is `m_long` and steps are read through bp.
 template <int M>
-__device__ __forceinline__ void scan_item(const ScanArgs &a, const uint16_t *lds,
-                                          int tile_paths, int path0,
+__device__ __forceinline__ void scan_item(const ScanArgs &a, const TileView &tv,
                                           const uint16_t *__restrict__ bp, int lane,
                                           uint32_t slot, uint32_t &cnt_good,
                                           uint32_t &cnt_bad)
@@ -402,18 +354,124 @@ __device__ __forceinline__ void scan_item(const ScanArgs &a, const uint16_t *lds
 #pragma unroll
         for (int t = 0; t < M; ++t) b[t] = 0;
     }
-    for (int p = 0; p < tile_paths; ++p) {
-        const uint16_t *img = lds + p * a.L.total;
-        PathView pv;
-        pv.first = img + a.L.first_at();
-        pv.next = img + a.L.next_at();
-        pv.step = img + a.L.step_at();
-        pv.n = __builtin_amdgcn_readfirstlane((int)img[a.L.len_at()]);
-        pv.a0 = __builtin_amdgcn_readfirstlane((uint32_t)pv.step[0]);
-        bool good, bad;
-        eval_item<M>(a, pv, b, bp, valid, lane, (uint32_t)(path0 + p), slot, good, bad);
-        uint32_t g = (uint32_t)__popcll(__ballot(good));
-        uint32_t d = (uint32_t)__popcll(__ballot(bad));
+    // bit p of pass: every node of this alignment occurs on tile path p, i.e.
+    // the alignment survives the filter of src/eval.cpp:81-91 for that path
+    uint32_t pass = valid ? tv.all_paths : 0u;
+    if (a.filter) {
+#pragma unroll
+        for (int t = 0; t < M; ++t) pass &= tv.nodemask[b[t] >> 1];
+    }
+    // positions of the path's first step inside B, refreshed when a0 changes
+    uint32_t cached_a0 = 0xFFFFFFFFu, a0_fw = 0, a0_rc = 0;
+
+    for (int p = 0; p < tv.tile_paths; ++p) {
+        const bool in = (pass >> p) & 1u;
+        if (!__any(in)) continue;
+        const int n = __builtin_amdgcn_readlane(tv.hdr_n, p);
+        const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)tv.hdr_a0, p);
+        const uint16_t *img = tv.lds + p * a.L.total;
+        const uint16_t *stepbase = img + a.L.step_at();
+
+        uint32_t e = in ? (uint32_t)img[a.L.first_at() + (b[0] >> 1)] : ENT_NONE;
+        const bool found =
+            subpath_search<M>(b, e, img + a.L.next_at(), stepbase, a.L.nm, n);
+        bool good = found;
+        bool bad = false;
+        const bool open = in && !found;
+        if (__any(open)) {
+            if (M > n) {                  // src/alignments.cpp:500 row-0 bound
+                good |= open;
+            } else {
+                // B is not a subpath and m <= n: the traceback stays free only
+                // if a proper suffix of B (or of rc(B)) equals a prefix of the
+                // path ("start-overhang").  Exact test; survivors go to k_dp.
+                if (a0 != cached_a0) {
+                    cached_a0 = a0;
+                    a0_fw = 0;
+                    a0_rc = 0;
+#pragma unroll
+                    for (int t = 1; t < M; ++t) a0_fw |= (b[t] == a0) ? (1u << t) : 0u;
+#pragma unroll
+                    for (int t = 0; t < M - 1; ++t)
+                        a0_rc |= ((b[t] ^ 1u) == a0) ? (1u << t) : 0u;
+                }
+                bool cand = false;
+                if (__any(open && (a0_fw | a0_rc) != 0u)) {
+#pragma unroll
+                    for (int t = 1; t < M; ++t) {      // B[t..M) == path[0..M-t) ?
+                        const bool live = open && ((a0_fw >> t) & 1u);
+                        if (__any(live))
+                            cand |= tail_equals(bp, t, 1, M - t, 0u, stepbase, live);
+                    }
+#pragma unroll
+                    for (int t = 0; t < M - 1; ++t) {  // rc(B)[M-1-t..M) == path[0..t+1) ?
+                        const bool live = open && ((a0_rc >> t) & 1u);
+                        if (__any(live))
+                            cand |= tail_equals(bp, t, -1, t + 1, 1u, stepbase, live);
+                    }
+                }
+                bad = open && !cand;
+                push_pairs(a, cand, lane, (uint32_t)(tv.path0 + p), slot);
+            }
+        }
+        const uint32_t g = (uint32_t)__popcll(__ballot(good));
+        const uint32_t d = (uint32_t)__popcll(__ballot(bad));
+        if (lane == p) {
+            cnt_good += g;
+            cnt_bad += d;
+        }
+    }
+}
+
+// Same decision for alignments too long for registers.
+__device__ __forceinline__ void scan_item_long(const ScanArgs &a, const TileView &tv,
+                                               const uint16_t *__restrict__ bp, int M,
+                                               int lane, uint32_t slot,
+                                               uint32_t &cnt_good, uint32_t &cnt_bad)
+{
+    const uint32_t first_step = bp[0];
+    const bool valid = first_step != STEP_INVALID;
+    const uint32_t b0 = valid ? first_step : 0u;
+    uint32_t pass = valid ? tv.all_paths : 0u;
+    if (a.filter) {
+        for (int t = 0; t < M; ++t) {
+            const uint32_t bt = valid ? (uint32_t)bp[t * WAVE] : 0u;
+            pass &= tv.nodemask[bt >> 1];
+        }
+    }
+    for (int p = 0; p < tv.tile_paths; ++p) {
+        const bool in = (pass >> p) & 1u;
+        if (!__any(in)) continue;
+        const int n = __builtin_amdgcn_readlane(tv.hdr_n, p);
+        const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)tv.hdr_a0, p);
+        const uint16_t *img = tv.lds + p * a.L.total;
+        const uint16_t *stepbase = img + a.L.step_at();
+        uint32_t e = in ? (uint32_t)img[a.L.first_at() + (b0 >> 1)] : ENT_NONE;
+        const bool found = subpath_search_long(bp, M, b0, e, img + a.L.next_at(),
+                                               stepbase, a.L.nm, n);
+        bool good = found;
+        bool bad = false;
+        const bool open = in && !found;
+        if (__any(open)) {
+            if (M > n) {
+                good |= open;
+            } else {
+                bool cand = false;
+                for (int t = 0; t < M; ++t) {
+                    const uint32_t bt = bp[t * WAVE];
+                    const bool live_fw = open && t >= 1 && bt == a0;
+                    if (__any(live_fw))
+                        cand |= tail_equals(bp, t, 1, M - t, 0u, stepbase, live_fw);
+                    const bool live_rc = open && t < M - 1 && (bt ^ 1u) == a0;
+                    if (__any(live_rc))
+                        cand |= tail_equals(bp, t, -1, t + 1, 1u, stepbase, live_rc);
+                }
+                bad = open && !cand;
+                push_pairs(a, cand, lane, (uint32_t)(tv.path0 + p), slot);
+            }
+        }
+        const uint32_t g = (uint32_t)__popcll(__ballot(good));
+        const uint32_t d = (uint32_t)__popcll(__ballot(bad));
         if (lane == p) {
             cnt_good += g;
             cnt_bad += d;
@@ -437,16 +495,36 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan(ScanArgs a)
     const int tile_id = within % a.n_tiles;
     const int chunk = (within / a.n_tiles) * 8 + xcd;
 
-    const int path0 = tile_id * a.tile;
-    const int tile_paths = min(a.tile, a.n_paths - path0);
+    TileView tv;
+    tv.path0 = tile_id * a.tile;
+    tv.tile_paths = min(a.tile, a.n_paths - tv.path0);
+    tv.all_paths = tv.tile_paths >= 32 ? 0xFFFFFFFFu : ((1u << tv.tile_paths) - 1u);
+    tv.lds = lds;
+    uint32_t *nodemask = reinterpret_cast<uint32_t *>(lds + (size_t)a.tile * a.L.total);
+    tv.nodemask = nodemask;
 
     // stage the tile's images: contiguous in HBM, 16 bytes per lane
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(
-            a.images + (size_t)path0 * a.L.total);
+            a.images + (size_t)tv.path0 * a.L.total);
         uint4 *dst = reinterpret_cast<uint4 *>(lds);
-        const int n16 = tile_paths * a.L.total / 8;
+        const int n16 = tv.tile_paths * a.L.total / 8;
         for (int i = tid; i < n16; i += SCAN_THREADS) dst[i] = src[i];
+    }
+    __syncthreads();
+    // which tile paths carry each node (the filter of src/eval.cpp:81-91 as a
+    // bit test): read off the first-occurrence tables just staged
+    for (int v = tid; v < a.L.v2; v += SCAN_THREADS) {
+        uint32_t m = 0;
+        for (int p = 0; p < tv.tile_paths; ++p)
+            m |= (lds[p * a.L.total + a.L.first_at() + v] != ENT_NONE) ? (1u << p) : 0u;
+        nodemask[v] = m;
+    }
+    tv.hdr_n = 0;
+    tv.hdr_a0 = STEP_NOMATCH;
+    if (lane < tv.tile_paths) {
+        tv.hdr_n = lds[lane * a.L.total + a.L.len_at()];
+        tv.hdr_a0 = lds[lane * a.L.total + a.L.step_at()];
     }
     __syncthreads();
 
@@ -461,35 +539,15 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan(ScanArgs a)
         switch (M) {
 #define GFAL_CASE(MM)                                                          \
     case MM:                                                                   \
-        scan_item<MM>(a, lds, tile_paths, path0, bp, lane, slot, cnt_good,     \
-                      cnt_bad);                                                \
+        scan_item<MM>(a, tv, bp, lane, slot, cnt_good, cnt_bad);               \
         break;
             GFAL_CASE(1) GFAL_CASE(2) GFAL_CASE(3) GFAL_CASE(4)
             GFAL_CASE(5) GFAL_CASE(6) GFAL_CASE(7) GFAL_CASE(8)
             GFAL_CASE(9) GFAL_CASE(10) GFAL_CASE(11) GFAL_CASE(12)
             GFAL_CASE(13) GFAL_CASE(14) GFAL_CASE(15) GFAL_CASE(16)
 #undef GFAL_CASE
-        default: {
-            const bool valid = bp[0] != STEP_INVALID;
-            for (int p = 0; p < tile_paths; ++p) {
-                const uint16_t *img = lds + p * a.L.total;
-                PathView pv;
-                pv.first = img + a.L.first_at();
-                pv.next = img + a.L.next_at();
-                pv.step = img + a.L.step_at();
-                pv.n = __builtin_amdgcn_readfirstlane((int)img[a.L.len_at()]);
-                pv.a0 = __builtin_amdgcn_readfirstlane((uint32_t)pv.step[0]);
-                bool good, bad;
-                eval_item_long(a, pv, bp, M, valid, lane, (uint32_t)(path0 + p),
-                               slot, good, bad);
-                uint32_t g = (uint32_t)__popcll(__ballot(good));
-                uint32_t d = (uint32_t)__popcll(__ballot(bad));
-                if (lane == p) {
-                    cnt_good += g;
-                    cnt_bad += d;
-                }
-            }
-        }
+        default:
+            scan_item_long(a, tv, bp, M, lane, slot, cnt_good, cnt_bad);
         }
     }
 
@@ -499,15 +557,15 @@ __global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan(ScanArgs a)
     uint32_t *red = reinterpret_cast<uint32_t *>(lds);
     if (tid < 2 * MAX_TILE) red[tid] = 0;
     __syncthreads();
-    if (lane < tile_paths) {
+    if (lane < tv.tile_paths) {
         if (cnt_bad) atomicAdd(&red[lane], cnt_bad);
         if (cnt_good) atomicAdd(&red[MAX_TILE + lane], cnt_good);
     }
     __syncthreads();
-    if (tid < tile_paths) {
+    if (tid < tv.tile_paths) {
         uint32_t d = red[tid], g = red[MAX_TILE + tid];
-        if (d) atomicAdd(&a.counts[path0 + tid], d);
-        if (g) atomicAdd(&a.counts[a.n_paths + path0 + tid], g);
+        if (d) atomicAdd(&a.counts[tv.path0 + tid], d);
+        if (g) atomicAdd(&a.counts[a.n_paths + tv.path0 + tid], g);
     }
 }
 
@@ -981,7 +1039,7 @@ int gfal_scorer_score_device(gfal_scorer *s, const int32_t *d_path_off,
 
     const ImageLayout L = make_layout(s->n_local, max_path_len);
     const size_t img_bytes = (size_t)L.total * sizeof(uint16_t);
-    if (img_bytes > (size_t)LDS_BUDGET) {
+    if (img_bytes + (size_t)L.v2 * sizeof(uint32_t) > (size_t)LDS_BUDGET) {
         set_err("path image of %zu bytes exceeds the LDS budget", img_bytes);
         return GFAL_E_RANGE;
     }
@@ -1017,7 +1075,9 @@ int gfal_scorer_score_device(gfal_scorer *s, const int32_t *d_path_off,
         a.images = s->d_images;
         a.L = L;
         a.n_paths = n_paths;
-        int tile = (int)std::min<size_t>((size_t)LDS_BUDGET / img_bytes, MAX_TILE);
+        const size_t mask_bytes = (size_t)L.v2 * sizeof(uint32_t);
+        int tile = (int)std::min<size_t>(((size_t)LDS_BUDGET - mask_bytes) / img_bytes,
+                                         MAX_TILE);
         tile = std::max(1, std::min(tile, (int)n_paths));
         a.tile = tile;
         a.n_tiles = (n_paths + tile - 1) / tile;
@@ -1036,7 +1096,7 @@ int gfal_scorer_score_device(gfal_scorer *s, const int32_t *d_path_off,
         a.wl_count = s->d_status + 1;
         a.wl_capacity = s->wl_capacity;
         a.status = s->d_status;
-        const size_t lds = std::max((size_t)tile * img_bytes,
+        const size_t lds = std::max((size_t)tile * img_bytes + mask_bytes,
                                     (size_t)2 * MAX_TILE * sizeof(uint32_t));
         const unsigned grid = (unsigned)a.n_tiles * (unsigned)a.n_chunks;
         hipLaunchKernelGGL(k_scan, dim3(grid), dim3(SCAN_THREADS), lds, st, a);
