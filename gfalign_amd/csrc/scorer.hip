@@ -16,8 +16,10 @@
 //               the T paths; ballot/popcount per (wave, path); one atomic per
 //               counter per workgroup.  Pairs the cheap rules cannot decide
 //               go to a worklist.
-//   k_dp        exact Needleman-Wunsch + traceback-exit propagation for the
-//               worklist (rare "start-overhang" pairs).
+//   k_wl_*      counting sort of the worklist by (length class, path).
+//   k_dp_*      exact Needleman-Wunsch + traceback-exit propagation for the
+//               worklist (rare "start-overhang" pairs); rows in registers
+//               for alignments of up to 32 steps.
 //   k_pairs     the same exact DP for every alignment of one path, both
 //               orientations (evalPath's per-alignment scores).
 //
@@ -226,8 +228,21 @@ struct ScanArgs {
     unsigned long long *worklist;
     uint32_t *wl_count;
     uint32_t wl_capacity;
+    uint32_t *wl_hist;        // [4 * n_paths] entries per (path, length class)
     uint32_t *status;
 };
+
+// Worklist entry: bit 63 = rc orientation has an overhang, bit 62 = fw has one,
+// bits 32..61 = path, bits 0..31 = slot (item * 64 + lane).
+constexpr unsigned long long WL_FW = 1ull << 62, WL_RC = 1ull << 63;
+constexpr uint32_t WL_PATH_MASK = 0x3FFFFFFFu;
+
+// Length classes of the DP kernel (rows held in 8 / 16 / 32 registers, or in
+// LDS / HBM for longer alignments).
+__host__ __device__ __forceinline__ int length_class(int m)
+{
+    return m <= 8 ? 0 : m <= 16 ? 1 : m <= 32 ? 2 : 3;
+}
 
 // What a wave keeps about the tile while it walks its items.
 struct TileView {
@@ -245,20 +260,28 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long m, int lane)
     return __popcll(m & ((1ull << lane) - 1ull));
 }
 
-// Append the lanes in `want` to the worklist.
-__device__ __forceinline__ void push_pairs(const ScanArgs &a, bool want, int lane,
-                                           uint32_t path_global, uint32_t slot)
+// Append the lanes in `want` to the worklist (fw / rc: which orientation has
+// the overhang) and count them in the (path, length class) histogram that the
+// counting sort in front of k_dp uses.
+__device__ __forceinline__ void push_pairs(const ScanArgs &a, bool fw, bool rc, int lane,
+                                           uint32_t path_global, uint32_t slot, int M)
 {
+    const bool want = fw || rc;
     unsigned long long m = __ballot(want);
     if (m == 0) return;
     uint32_t base = 0;
     int leader = __ffsll((long long)m) - 1;
-    if (lane == leader) base = atomicAdd(a.wl_count, (uint32_t)__popcll(m));
+    if (lane == leader) {
+        const uint32_t cnt = (uint32_t)__popcll(m);
+        base = atomicAdd(a.wl_count, cnt);
+        atomicAdd(&a.wl_hist[(uint32_t)length_class(M) * (uint32_t)a.n_paths + path_global], cnt);
+    }
     base = __shfl(base, leader, WAVE);
     if (want) {
         uint32_t idx = base + lanes_below(m, lane);
         if (idx < a.wl_capacity)
-            a.worklist[idx] = ((unsigned long long)path_global << 32) | slot;
+            a.worklist[idx] = (fw ? WL_FW : 0ull) | (rc ? WL_RC : 0ull) |
+                              ((unsigned long long)path_global << 32) | slot;
         else
             atomicOr(a.status, ST_DP_OVERFLOW);
     }
@@ -395,23 +418,23 @@ __device__ __forceinline__ void scan_item(const ScanArgs &a, const TileView &tv,
                     for (int t = 0; t < M - 1; ++t)
                         a0_rc |= ((b[t] ^ 1u) == a0) ? (1u << t) : 0u;
                 }
-                bool cand = false;
+                bool cand_fw = false, cand_rc = false;
                 if (__any(open && (a0_fw | a0_rc) != 0u)) {
 #pragma unroll
                     for (int t = 1; t < M; ++t) {      // B[t..M) == path[0..M-t) ?
                         const bool live = open && ((a0_fw >> t) & 1u);
                         if (__any(live))
-                            cand |= tail_equals(bp, t, 1, M - t, 0u, stepbase, live);
+                            cand_fw |= tail_equals(bp, t, 1, M - t, 0u, stepbase, live);
                     }
 #pragma unroll
                     for (int t = 0; t < M - 1; ++t) {  // rc(B)[M-1-t..M) == path[0..t+1) ?
                         const bool live = open && ((a0_rc >> t) & 1u);
                         if (__any(live))
-                            cand |= tail_equals(bp, t, -1, t + 1, 1u, stepbase, live);
+                            cand_rc |= tail_equals(bp, t, -1, t + 1, 1u, stepbase, live);
                     }
                 }
-                bad = open && !cand;
-                push_pairs(a, cand, lane, (uint32_t)(tv.path0 + p), slot);
+                bad = open && !(cand_fw || cand_rc);
+                push_pairs(a, cand_fw, cand_rc, lane, (uint32_t)(tv.path0 + p), slot, M);
             }
         }
         const uint32_t g = (uint32_t)__popcll(__ballot(good));
@@ -456,18 +479,18 @@ __device__ __forceinline__ void scan_item_long(const ScanArgs &a, const TileView
             if (M > n) {
                 good |= open;
             } else {
-                bool cand = false;
+                bool cand_fw = false, cand_rc = false;
                 for (int t = 0; t < M; ++t) {
                     const uint32_t bt = bp[t * WAVE];
                     const bool live_fw = open && t >= 1 && bt == a0;
                     if (__any(live_fw))
-                        cand |= tail_equals(bp, t, 1, M - t, 0u, stepbase, live_fw);
+                        cand_fw |= tail_equals(bp, t, 1, M - t, 0u, stepbase, live_fw);
                     const bool live_rc = open && t < M - 1 && (bt ^ 1u) == a0;
                     if (__any(live_rc))
-                        cand |= tail_equals(bp, t, -1, t + 1, 1u, stepbase, live_rc);
+                        cand_rc |= tail_equals(bp, t, -1, t + 1, 1u, stepbase, live_rc);
                 }
-                bad = open && !cand;
-                push_pairs(a, cand, lane, (uint32_t)(tv.path0 + p), slot);
+                bad = open && !(cand_fw || cand_rc);
+                push_pairs(a, cand_fw, cand_rc, lane, (uint32_t)(tv.path0 + p), slot, M);
             }
         }
         const uint32_t g = (uint32_t)__popcll(__ballot(good));
@@ -655,35 +678,214 @@ __device__ __forceinline__ uint32_t *dp_row(uint32_t *row_scratch, int &stride)
     return row_scratch + blockIdx.x * DP_THREADS + threadIdx.x;
 }
 
-template <bool ROWS_IN_LDS>
-__global__ __launch_bounds__(DP_THREADS) void k_dp(
-    Items items, const uint16_t *__restrict__ images, ImageLayout L, int n_paths,
-    const unsigned long long *__restrict__ worklist,
+// The same fill with the row in registers: MC columns, fully unrolled.
+// b[] holds the (oriented) alignment, padded with STEP_INVALID; columns beyond
+// the lane's own m are computed and ignored (nothing flows from a column to
+// its left).  A lane with n == 0 does no work.
+template <int MC>
+__device__ __forceinline__ int traceback_score_regs(const uint16_t *__restrict__ astep,
+                                                    int n, const uint32_t (&b)[MC], int m)
+{
+    int dp[MC + 1], x[MC + 1];
+#pragma unroll
+    for (int j = 0; j <= MC; ++j) {
+        dp[j] = (j <= n) ? -j : 0;
+        x[j] = dp[j];
+    }
+    for (int i = 1; i <= n; ++i) {
+        const uint32_t ai = astep[i - 1];
+        int diag_dp = dp[0], diag_x = x[0];
+        dp[0] = 0;
+        x[0] = 0;
+        int left_dp = 0, left_x = 0;
+#pragma unroll
+        for (int j = 1; j <= MC; ++j) {
+            const int up_dp = dp[j], up_x = x[j];
+            const int d = diag_dp + ((ai == b[j - 1]) ? 0 : -1);
+            const int u = up_dp + ((j < m) ? -1 : 0);
+            const int l = left_dp - 1;
+            const int v = max(d, max(u, l));
+            const int xx = (v == d) ? diag_x : ((up_dp >= left_dp) ? up_x : left_x);
+            dp[j] = v;
+            x[j] = xx;
+            diag_dp = up_dp;
+            diag_x = up_x;
+            left_dp = v;
+            left_x = xx;
+        }
+    }
+    int r = 0;
+#pragma unroll
+    for (int j = 1; j <= MC; ++j) r = (j == m) ? dp[j] - x[j] : r;
+    return r;
+}
+
+// One worklist entry per lane: both orientations that were flagged, rows in
+// registers.  `second` lanes (both orientations flagged) run a second fill;
+// the others idle through it with n = 0.
+template <int MC>
+__device__ __forceinline__ bool dp_decide_regs(const uint16_t *__restrict__ astep, int n,
+                                               const uint16_t *__restrict__ bp, int m,
+                                               bool has_fw, bool has_rc)
+{
+    uint32_t b[MC];
+    // first orientation: fw if flagged, else rc
+    const bool first_rc = !has_fw;
+#pragma unroll
+    for (int j = 0; j < MC; ++j) {
+        const int src = first_rc ? (m - 1 - j) : j;
+        uint32_t v = STEP_INVALID;
+        if (j < m) v = (uint32_t)bp[src * WAVE] ^ (first_rc ? 1u : 0u);
+        b[j] = v;
+    }
+    bool good = traceback_score_regs<MC>(astep, n, b, m) == 0 && n > 0;
+    const bool second = has_fw && has_rc;
+    if (__any(second)) {
+#pragma unroll
+        for (int j = 0; j < MC; ++j) {
+            uint32_t v = STEP_INVALID;
+            if (j < m) v = (uint32_t)bp[(m - 1 - j) * WAVE] ^ 1u;
+            b[j] = v;
+        }
+        const int n2 = second ? n : 0;
+        good |= traceback_score_regs<MC>(astep, n2, b, m) == 0 && n2 > 0;
+    }
+    return good;
+}
+
+// Counting sort of the worklist by (length class, path): each class becomes a
+// contiguous range for its own k_dp launch, and consecutive lanes share the
+// path (same n, same steps: broadcast loads).  Order only affects speed; any order gives the same counters.
+__global__ __launch_bounds__(1024) void k_wl_offsets(const uint32_t *__restrict__ hist,
+                                                      uint32_t *__restrict__ offsets,
+                                                      uint32_t *__restrict__ cursor,
+                                                      int n_bins)
+{
+    __shared__ uint32_t part[1024];
+    const int tid = threadIdx.x;
+    const int per = (n_bins + 1023) / 1024;
+    const int lo = min(tid * per, n_bins), hi = min(lo + per, n_bins);
+    uint32_t sum = 0;
+    for (int i = lo; i < hi; ++i) sum += hist[i];
+    part[tid] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {      // Hillis-Steele inclusive scan
+        uint32_t v = tid >= o ? part[tid - o] : 0u;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[tid] - sum;
+    for (int i = lo; i < hi; ++i) {
+        offsets[i] = run;
+        cursor[i] = 0;
+        run += hist[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_wl_scatter(
+    Items items, const unsigned long long *__restrict__ worklist,
     const uint32_t *__restrict__ wl_count, uint32_t wl_capacity,
-    uint32_t *__restrict__ row_scratch, uint32_t *__restrict__ counts)
+    const uint32_t *__restrict__ offsets, uint32_t *__restrict__ cursor,
+    uint32_t n_paths, unsigned long long *__restrict__ sorted)
+{
+    const uint32_t total = min(*wl_count, wl_capacity);
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < total; w += stride) {
+        const unsigned long long ent = worklist[w];
+        const uint32_t p = (uint32_t)(ent >> 32) & WL_PATH_MASK;
+        const uint32_t it = (uint32_t)ent >> 6;
+        const uint32_t bin = (uint32_t)length_class((int)items.len[it]) * n_paths + p;
+        const uint32_t at = offsets[bin] + atomicAdd(&cursor[bin], 1u);
+        sorted[at] = ent;
+    }
+}
+
+// Range of the sorted worklist that holds length class `cls`.
+__device__ __forceinline__ void class_range(const uint32_t *offsets, int n_paths, int cls,
+                                            uint32_t total, uint32_t &lo, uint32_t &hi)
+{
+    lo = min(offsets[cls * n_paths], total);
+    hi = cls == 3 ? total : min(offsets[(cls + 1) * n_paths], total);
+}
+
+struct DpArgs {
+    Items items;
+    const uint16_t *images;
+    ImageLayout L;
+    int n_paths;
+    const unsigned long long *sorted;
+    const uint32_t *offsets;
+    const uint32_t *wl_count;
+    uint32_t wl_capacity;
+    uint32_t *row_scratch;
+    uint32_t *counts;
+};
+
+struct DpEntry {
+    uint32_t p;
+    const uint16_t *astep, *bp;
+    int n, m;
+    bool has_fw, has_rc;
+};
+
+__device__ __forceinline__ DpEntry load_entry(const DpArgs &a, uint32_t w, bool live)
+{
+    const unsigned long long ent = live ? a.sorted[w] : 0ull;
+    DpEntry e;
+    e.p = (uint32_t)(ent >> 32) & WL_PATH_MASK;
+    const uint32_t slot = (uint32_t)ent;
+    const uint32_t it = slot >> 6, ln = slot & 63u;
+    const uint16_t *img = a.images + (size_t)e.p * a.L.total;
+    e.astep = img + a.L.step_at();
+    e.n = live ? (int)img[a.L.len_at()] : 0;
+    e.m = live ? (int)a.items.len[it] : 0;
+    e.bp = a.items.steps + (size_t)(live ? a.items.base[it] : 0u) * WAVE + ln;
+    e.has_fw = (ent & WL_FW) != 0;
+    e.has_rc = (ent & WL_RC) != 0;
+    return e;
+}
+
+// Length classes 0..2: rows in MC registers.
+template <int MC, int CLS>
+__global__ __launch_bounds__(DP_THREADS) void k_dp_regs(DpArgs a)
+{
+    const uint32_t total = min(*a.wl_count, a.wl_capacity);
+    uint32_t lo, hi;
+    class_range(a.offsets, a.n_paths, CLS, total, lo, hi);
+    const uint32_t n_threads = gridDim.x * DP_THREADS;
+    for (uint32_t w0 = lo + blockIdx.x * DP_THREADS; w0 < hi; w0 += n_threads) {
+        const uint32_t w = w0 + threadIdx.x;
+        const bool live = w < hi;
+        const DpEntry e = load_entry(a, w, live);
+        const bool good = dp_decide_regs<MC>(e.astep, e.n, e.bp, e.m, e.has_fw, e.has_rc);
+        if (live) atomicAdd(&a.counts[(good ? a.n_paths : 0) + e.p], 1u);
+    }
+}
+
+// Length class 3 (more than 32 steps): rows in LDS or HBM.
+template <bool ROWS_IN_LDS>
+__global__ __launch_bounds__(DP_THREADS) void k_dp_long(DpArgs a)
 {
     int stride;
-    uint32_t *row = dp_row<ROWS_IN_LDS>(row_scratch, stride);
+    uint32_t *row = dp_row<ROWS_IN_LDS>(a.row_scratch, stride);
+    const uint32_t total = min(*a.wl_count, a.wl_capacity);
+    uint32_t lo, hi;
+    class_range(a.offsets, a.n_paths, 3, total, lo, hi);
     const uint32_t n_threads = gridDim.x * DP_THREADS;
-    const uint32_t gtid = blockIdx.x * DP_THREADS + threadIdx.x;
-    const uint32_t total = min(*wl_count, wl_capacity);
-    for (uint32_t w = gtid; w < total; w += n_threads) {
-        const unsigned long long ent = worklist[w];
-        const uint32_t p = (uint32_t)(ent >> 32);
-        const uint32_t slot = (uint32_t)ent;
-        const uint32_t it = slot >> 6, ln = slot & 63u;
-        const uint16_t *img = images + (size_t)p * L.total;
-        StepsA A{img + L.step_at(), (int)img[L.len_at()]};
-        StepsB B{items.steps + (size_t)items.base[it] * WAVE + ln,
-                 (int)items.len[it], 0u};
-        // src/eval.cpp:92-98: good iff either orientation tracebacks for free.
-        // Both fills always run (no per-lane early exit: the lanes of a wave
-        // stay in step through the row loops).
+    for (uint32_t w0 = lo + blockIdx.x * DP_THREADS; w0 < hi; w0 += n_threads) {
+        const uint32_t w = w0 + threadIdx.x;
+        const bool live = w < hi;
+        const DpEntry e = load_entry(a, w, live);
+        // src/eval.cpp:92-98; both fills always run so the lanes of the wave
+        // stay in step through the row loops (a dead lane has n = m = 0)
+        StepsA A{e.astep, e.n};
+        StepsB B{e.bp, e.m, 0u};
         const int fw = traceback_score(A, B, row, stride);
         B.flip = 1u;
         const int rc = traceback_score(A, B, row, stride);
         const bool good = fw == 0 || rc == 0;
-        atomicAdd(&counts[(good ? n_paths : 0) + p], 1u);
+        if (live) atomicAdd(&a.counts[(good ? a.n_paths : 0) + e.p], 1u);
     }
 }
 
@@ -739,8 +941,11 @@ struct gfal_scorer {
     uint16_t *d_item_len = nullptr;
     int32_t *d_slot_orig = nullptr;    // [n_items*64] original index or -1
     uint32_t *d_status = nullptr;      // [2]: status word, worklist count
-    unsigned long long *d_worklist = nullptr;
+    unsigned long long *d_worklist = nullptr;   // as pushed by k_scan
+    unsigned long long *d_worklist_sorted = nullptr;
     uint32_t wl_capacity = 0;
+    uint32_t *d_wl_bins = nullptr;     // [3][4 * n_paths]: hist | offsets | cursor
+    size_t wl_bins_cap = 0;
     uint32_t *d_rows = nullptr;        // DP row scratch
     uint16_t *d_images = nullptr;
     size_t images_cap = 0;             // uint16 units
@@ -794,6 +999,7 @@ void free_scorer(gfal_scorer *s)
     (void)hipSetDevice(s->device);
     void *bufs[] = {s->d_node_local, s->d_node_hist, s->d_item_steps, s->d_item_base,
                     s->d_item_len,   s->d_slot_orig, s->d_status,     s->d_worklist,
+                    s->d_worklist_sorted, s->d_wl_bins,
                     s->d_rows,       s->d_images,    s->d_path_off,   s->d_path_steps,
                     s->d_counts};
     for (void *b : bufs)
@@ -1001,6 +1207,8 @@ int gfal_scorer_create(const int32_t *aln_off, const int32_t *aln_steps,
     s->wl_capacity = (uint32_t)std::max<int64_t>(n_aln, (int64_t)1 << 22);
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_worklist),
                          (size_t)s->wl_capacity * sizeof(unsigned long long)));
+    CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_worklist_sorted),
+                         (size_t)s->wl_capacity * sizeof(unsigned long long)));
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_rows),
                          (size_t)row_scratch_words(max_len) * sizeof(uint32_t)));
 
@@ -1051,7 +1259,17 @@ int gfal_scorer_score_device(gfal_scorer *s, const int32_t *d_path_off,
             int rc = dev_reserve(&s->d_images, &s->images_cap, want);
             if (rc) return rc;
         }
+        size_t bins = (size_t)3 * 4 * n_paths;
+        if (bins > s->wl_bins_cap) {
+            if (s->have_last) HIP_TRY(hipStreamSynchronize(s->last_stream));
+            int rc = dev_reserve(&s->d_wl_bins, &s->wl_bins_cap, bins);
+            if (rc) return rc;
+        }
     }
+    const int n_bins = 4 * n_paths;
+    uint32_t *d_hist = s->d_wl_bins, *d_offsets = s->d_wl_bins + n_bins,
+             *d_cursor = s->d_wl_bins + 2 * (size_t)n_bins;
+    HIP_TRY(hipMemsetAsync(d_hist, 0, (size_t)n_bins * sizeof(uint32_t), st));
 
     HIP_TRY(hipMemsetAsync(s->d_status, 0, 2 * sizeof(uint32_t), st));
     hipEvent_t *ev = s->ev[s->ev_calls % gfal_scorer::EV_RING];
@@ -1095,6 +1313,7 @@ int gfal_scorer_score_device(gfal_scorer *s, const int32_t *d_path_off,
         a.worklist = s->d_worklist;
         a.wl_count = s->d_status + 1;
         a.wl_capacity = s->wl_capacity;
+        a.wl_hist = d_hist;
         a.status = s->d_status;
         const size_t lds = std::max((size_t)tile * img_bytes + mask_bytes,
                                     (size_t)2 * MAX_TILE * sizeof(uint32_t));
@@ -1106,15 +1325,35 @@ int gfal_scorer_score_device(gfal_scorer *s, const int32_t *d_path_off,
         s->last_lds = (int)lds;
         if (s->profiling) HIP_TRY(hipEventRecord(ev[2], st));
 
-        if (dp_rows_fit_lds(s->max_aln_len))
-            hipLaunchKernelGGL(k_dp<true>, dim3(DP_BLOCKS), dim3(DP_THREADS),
-                               dp_lds_bytes(s->max_aln_len), st, a.items, s->d_images, L,
-                               (int)n_paths, s->d_worklist, s->d_status + 1,
-                               s->wl_capacity, s->d_rows, d_counts);
-        else
-            hipLaunchKernelGGL(k_dp<false>, dim3(DP_BLOCKS), dim3(DP_THREADS), 0, st,
-                               a.items, s->d_images, L, (int)n_paths, s->d_worklist,
-                               s->d_status + 1, s->wl_capacity, s->d_rows, d_counts);
+        hipLaunchKernelGGL(k_wl_offsets, dim3(1), dim3(1024), 0, st, d_hist, d_offsets,
+                           d_cursor, n_bins);
+        hipLaunchKernelGGL(k_wl_scatter, dim3(256), dim3(256), 0, st, a.items,
+                           s->d_worklist, s->d_status + 1, s->wl_capacity, d_offsets,
+                           d_cursor, (uint32_t)n_paths, s->d_worklist_sorted);
+        DpArgs d;
+        d.items = a.items;
+        d.images = s->d_images;
+        d.L = L;
+        d.n_paths = n_paths;
+        d.sorted = s->d_worklist_sorted;
+        d.offsets = d_offsets;
+        d.wl_count = s->d_status + 1;
+        d.wl_capacity = s->wl_capacity;
+        d.row_scratch = s->d_rows;
+        d.counts = d_counts;
+        hipLaunchKernelGGL((k_dp_regs<8, 0>), dim3(DP_BLOCKS), dim3(DP_THREADS), 0, st, d);
+        if (s->max_aln_len > 8)
+            hipLaunchKernelGGL((k_dp_regs<16, 1>), dim3(DP_BLOCKS), dim3(DP_THREADS), 0, st, d);
+        if (s->max_aln_len > 16)
+            hipLaunchKernelGGL((k_dp_regs<32, 2>), dim3(DP_BLOCKS), dim3(DP_THREADS), 0, st, d);
+        if (s->max_aln_len > 32) {
+            if (dp_rows_fit_lds(s->max_aln_len))
+                hipLaunchKernelGGL(k_dp_long<true>, dim3(DP_BLOCKS), dim3(DP_THREADS),
+                                   dp_lds_bytes(s->max_aln_len), st, d);
+            else
+                hipLaunchKernelGGL(k_dp_long<false>, dim3(DP_BLOCKS), dim3(DP_THREADS), 0,
+                                   st, d);
+        }
         HIP_TRY(hipGetLastError());
     } else if (s->profiling) {
         HIP_TRY(hipEventRecord(ev[2], st));

@@ -84,6 +84,23 @@ def test_fuzz_walks(gpu, seed):
     check(alns, paths, 32)
 
 
+@pytest.mark.parametrize("max_m,max_n", [(16, 24), (32, 40), (48, 64)])
+def test_fuzz_dp_length_classes(gpu, max_m, max_n):
+    """Two or three nodes and long alignments: start-overhangs in every
+    length class of the exact-DP kernels (rows in 8/16/32 registers, LDS)."""
+    rnd = random.Random(100 + max_m)
+    alns, paths = random_case(rnd, rnd.randint(2, 3), 1200, 60, max_m, max_n,
+                              min_m=max(1, max_m // 2 - 2), min_n=max_m // 2)
+    aoff, ast = csr(alns)
+    poff, pst = csr(paths)
+    with Scorer(aoff, ast, 4) as sc:
+        got = sc.evaluate_paths(poff, pst, True)
+        assert sc.info()["dp_pairs"] > 500
+    exp = oracle.evaluate_paths(aoff, ast, poff, pst, True)
+    for g, e in zip(got, exp):
+        assert np.array_equal(g, e)
+
+
 def test_long_alignments_take_the_generic_path(gpu):
     """Alignments longer than the 16 register-resident steps."""
     rnd = random.Random(6)
