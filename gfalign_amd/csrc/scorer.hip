@@ -38,7 +38,7 @@
 namespace {
 
 constexpr int WAVE = 64;
-constexpr int SCAN_THREADS = 512;
+constexpr int SCAN_THREADS = 768;
 constexpr int SCAN_WAVES = SCAN_THREADS / WAVE;
 constexpr int MAX_REG_M = 16;          // alignments up to this length live in VGPRs
 constexpr int MAX_TILE = 32;           // one bit per tile path in the node masks
@@ -267,7 +267,7 @@ __device__ __forceinline__ void push_pairs(const ScanArgs &a, bool fw, bool rc, 
                                            uint32_t path_global, uint32_t slot, int M)
 {
     const bool want = fw || rc;
-    unsigned long long m = __ballot(want);
+    unsigned long long m = __builtin_amdgcn_ballot_w64(want);
     if (m == 0) return;
     uint32_t base = 0;
     int leader = __ffsll((long long)m) - 1;
@@ -300,36 +300,42 @@ __device__ __forceinline__ bool tail_equals(const uint16_t *__restrict__ bp, int
     return eq;
 }
 
+// Wave vote without the bool -> int round trip of __any().
+#define WAVE_ANY(pred) (__builtin_amdgcn_ballot_w64(pred) != 0ull)
+
 // Occurrence-chain search (DESIGN.md "k_scan"): is B a contiguous subpath of
 // the path, or of its reverse complement?  `e` = chain head for B[0]'s node.
 // Both directions are forward scans: the image holds the path's steps and,
-// behind them, the steps of its reverse complement.
+// behind them, the steps of its reverse complement.  The body is branch-free
+// (selects only); the single branch is the wave-level loop test.
 template <int M>
 __device__ __forceinline__ bool subpath_search(const uint32_t (&b)[M], uint32_t e,
                                                const uint16_t *next,
                                                const uint16_t *stepbase, int nm, int n)
 {
     bool found = false;
-    const uint32_t b0 = b[0];
-    while (__any(e != ENT_NONE)) {
-        if (e != ENT_NONE) {
-            const int pos = (int)(e & ENT_POS);
-            // dir 0: the path step at pos equals b0 -> B may start here.
-            // dir 1: it is b0's complement -> rc(B) may end here, i.e. B may
-            //        start at n-1-pos of the reverse-complemented path.
-            const uint32_t dir = (e >> 15) ^ (b0 & 1u);
-            const bool fits = !(e & ENT_NOMATCH) &&
-                              (dir ? (pos >= M - 1) : (pos + M <= n));
-            // lanes whose window does not fit re-read stepbase[0..M) (in range)
-            const int at = fits ? (dir ? nm + (n - 1 - pos) : pos) : 0;
-            const uint16_t *w = stepbase + at;
-            bool ok = fits;
+    const uint32_t o0 = b[0] & 1u;
+    const uint32_t rc_origin = (uint32_t)(nm + n - 1);
+    do {
+        const bool act = e != ENT_NONE;
+        const uint32_t pos = e & ENT_POS;
+        // dir 0: the path step at pos equals b0 -> B may start here.
+        // dir 1: it is b0's complement -> rc(B) may end here, i.e. B may
+        //        start at n-1-pos of the reverse-complemented path.
+        const bool dir = (((e >> 15) ^ o0) & 1u) != 0u;
+        const bool room = dir ? (pos >= (uint32_t)(M - 1)) : ((int)pos + M <= n);
+        // ENT_NONE has the ENT_NOMATCH bit set, so dead lanes never fit
+        const bool fits = room && (e & ENT_NOMATCH) == 0u;
+        // lanes whose window does not fit re-read stepbase[0..M) (in range)
+        const uint32_t at = fits ? (dir ? rc_origin - pos : pos) : 0u;
+        const uint16_t *w = stepbase + at;
+        const uint32_t nx = next[act ? pos : 0u];
+        bool ok = fits;
 #pragma unroll
-            for (int t = 1; t < M; ++t) ok &= (uint32_t)w[t] == b[t];
-            found |= ok;
-            e = found ? ENT_NONE : (uint32_t)next[pos];
-        }
-    }
+        for (int t = 1; t < M; ++t) ok &= (uint32_t)w[t] == b[t];
+        found |= ok;
+        e = (found || !act) ? ENT_NONE : nx;
+    } while (WAVE_ANY(e != ENT_NONE));
     return found;
 }
 
@@ -340,24 +346,26 @@ __device__ __forceinline__ bool subpath_search_long(const uint16_t *__restrict__
                                                     int n)
 {
     bool found = false;
-    while (__any(e != ENT_NONE)) {
-        if (e != ENT_NONE) {
-            const int pos = (int)(e & ENT_POS);
-            const uint32_t dir = (e >> 15) ^ (b0 & 1u);
-            const bool fits = !(e & ENT_NOMATCH) &&
-                              (dir ? (pos >= M - 1) : (pos + M <= n));
-            const int at = fits ? (dir ? nm + (n - 1 - pos) : pos) : 0;
-            const uint16_t *w = stepbase + at;
-            bool ok = fits;
-            // wave-uniform trip count; lanes that already failed keep reading
-            // (in range: at + t < at + M) instead of leaving the loop early
-            const int lim = __any(fits) ? M : 1;
-            for (int t = 1; t < lim; ++t)
-                ok &= (!fits) || (uint32_t)w[t] == (uint32_t)bp[t * WAVE];
-            found |= ok;
-            e = found ? ENT_NONE : (uint32_t)next[pos];
-        }
-    }
+    const uint32_t o0 = b0 & 1u;
+    const uint32_t rc_origin = (uint32_t)(nm + n - 1);
+    do {
+        const bool act = e != ENT_NONE;
+        const uint32_t pos = e & ENT_POS;
+        const bool dir = (((e >> 15) ^ o0) & 1u) != 0u;
+        const bool room = dir ? ((int)pos >= M - 1) : ((int)pos + M <= n);
+        const bool fits = room && (e & ENT_NOMATCH) == 0u;
+        const uint32_t at = fits ? (dir ? rc_origin - pos : pos) : 0u;
+        const uint16_t *w = stepbase + at;
+        const uint32_t nx = next[act ? pos : 0u];
+        bool ok = fits;
+        // wave-uniform trip count; a lane that does not fit compares against
+        // stepbase[0] throughout (in range) and stays false
+        const int lim = WAVE_ANY(fits) ? M : 1;
+        for (int t = 1; t < lim; ++t)
+            ok &= (uint32_t)w[fits ? t : 0] == (uint32_t)bp[t * WAVE];
+        found |= ok;
+        e = (found || !act) ? ENT_NONE : nx;
+    } while (WAVE_ANY(e != ENT_NONE));
     return found;
 }
 
@@ -389,7 +397,7 @@ __device__ __forceinline__ void scan_item(const ScanArgs &a, const TileView &tv,
 
     for (int p = 0; p < tv.tile_paths; ++p) {
         const bool in = (pass >> p) & 1u;
-        if (!__any(in)) continue;
+        if (!WAVE_ANY(in)) continue;
         const int n = __builtin_amdgcn_readlane(tv.hdr_n, p);
         const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)tv.hdr_a0, p);
         const uint16_t *img = tv.lds + p * a.L.total;
@@ -401,7 +409,7 @@ __device__ __forceinline__ void scan_item(const ScanArgs &a, const TileView &tv,
         bool good = found;
         bool bad = false;
         const bool open = in && !found;
-        if (__any(open)) {
+        if (WAVE_ANY(open)) {
             if (M > n) {                  // src/alignments.cpp:500 row-0 bound
                 good |= open;
             } else {
@@ -419,17 +427,17 @@ __device__ __forceinline__ void scan_item(const ScanArgs &a, const TileView &tv,
                         a0_rc |= ((b[t] ^ 1u) == a0) ? (1u << t) : 0u;
                 }
                 bool cand_fw = false, cand_rc = false;
-                if (__any(open && (a0_fw | a0_rc) != 0u)) {
+                if (WAVE_ANY(open && (a0_fw | a0_rc) != 0u)) {
 #pragma unroll
                     for (int t = 1; t < M; ++t) {      // B[t..M) == path[0..M-t) ?
                         const bool live = open && ((a0_fw >> t) & 1u);
-                        if (__any(live))
+                        if (WAVE_ANY(live))
                             cand_fw |= tail_equals(bp, t, 1, M - t, 0u, stepbase, live);
                     }
 #pragma unroll
                     for (int t = 0; t < M - 1; ++t) {  // rc(B)[M-1-t..M) == path[0..t+1) ?
                         const bool live = open && ((a0_rc >> t) & 1u);
-                        if (__any(live))
+                        if (WAVE_ANY(live))
                             cand_rc |= tail_equals(bp, t, -1, t + 1, 1u, stepbase, live);
                     }
                 }
@@ -437,8 +445,8 @@ __device__ __forceinline__ void scan_item(const ScanArgs &a, const TileView &tv,
                 push_pairs(a, cand_fw, cand_rc, lane, (uint32_t)(tv.path0 + p), slot, M);
             }
         }
-        const uint32_t g = (uint32_t)__popcll(__ballot(good));
-        const uint32_t d = (uint32_t)__popcll(__ballot(bad));
+        const uint32_t g = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(good));
+        const uint32_t d = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(bad));
         if (lane == p) {
             cnt_good += g;
             cnt_bad += d;
@@ -464,7 +472,7 @@ __device__ __forceinline__ void scan_item_long(const ScanArgs &a, const TileView
     }
     for (int p = 0; p < tv.tile_paths; ++p) {
         const bool in = (pass >> p) & 1u;
-        if (!__any(in)) continue;
+        if (!WAVE_ANY(in)) continue;
         const int n = __builtin_amdgcn_readlane(tv.hdr_n, p);
         const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)tv.hdr_a0, p);
         const uint16_t *img = tv.lds + p * a.L.total;
@@ -475,7 +483,7 @@ __device__ __forceinline__ void scan_item_long(const ScanArgs &a, const TileView
         bool good = found;
         bool bad = false;
         const bool open = in && !found;
-        if (__any(open)) {
+        if (WAVE_ANY(open)) {
             if (M > n) {
                 good |= open;
             } else {
@@ -483,18 +491,18 @@ __device__ __forceinline__ void scan_item_long(const ScanArgs &a, const TileView
                 for (int t = 0; t < M; ++t) {
                     const uint32_t bt = bp[t * WAVE];
                     const bool live_fw = open && t >= 1 && bt == a0;
-                    if (__any(live_fw))
+                    if (WAVE_ANY(live_fw))
                         cand_fw |= tail_equals(bp, t, 1, M - t, 0u, stepbase, live_fw);
                     const bool live_rc = open && t < M - 1 && (bt ^ 1u) == a0;
-                    if (__any(live_rc))
+                    if (WAVE_ANY(live_rc))
                         cand_rc |= tail_equals(bp, t, -1, t + 1, 1u, stepbase, live_rc);
                 }
                 bad = open && !(cand_fw || cand_rc);
                 push_pairs(a, cand_fw, cand_rc, lane, (uint32_t)(tv.path0 + p), slot, M);
             }
         }
-        const uint32_t g = (uint32_t)__popcll(__ballot(good));
-        const uint32_t d = (uint32_t)__popcll(__ballot(bad));
+        const uint32_t g = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(good));
+        const uint32_t d = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(bad));
         if (lane == p) {
             cnt_good += g;
             cnt_bad += d;
@@ -502,7 +510,7 @@ __device__ __forceinline__ void scan_item_long(const ScanArgs &a, const TileView
     }
 }
 
-__global__ __launch_bounds__(SCAN_THREADS, 4) void k_scan(ScanArgs a)
+__global__ __launch_bounds__(SCAN_THREADS, 6) void k_scan(ScanArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     const int tid = threadIdx.x;
