@@ -1,0 +1,470 @@
+// main.cpp -- `gfalign` command line for the tools that sit on the scoring hot
+// path: search, evalPath, filter (and evalGFA's alignment summary).  Option
+// names, messages and stdout follow reference src/main.cpp / src/eval.cpp /
+// src/alignments.cpp; the scoring itself runs on the MI355X through
+// include/gfalign_scorer.h.  `align` (shells out to GraphAligner) and
+// `subgraph` (pure gfalibs) are out of scope.
+#include <getopt.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iomanip>
+#include <iostream>
+#include <set>
+#include <sstream>
+#include <string>
+#include <unordered_set>
+#include <vector>
+
+#include "graph_io.h"
+#include "search.h"
+
+using namespace gfal;
+
+namespace {
+
+const char *VERSION = "0.0.1";   // reference src/main.cpp:49
+
+struct Options {
+    int mode = -1;
+    std::string gfa, gaf, node_file, source, destination, path, out_file;
+    uint32_t max_steps = 100000, min_nodes = 0;
+    int return_all_paths = 0, cmd_flag = 0, stats_flag = 0, sort_alignment = 0;
+    int terminal_alignments = 0;
+    int device = 0;
+};
+
+int verbose_flag = 0;
+
+void require_file(const char *path)   // gfalibs ifFileExists
+{
+    if (access(path, F_OK) == -1) {
+        fprintf(stderr, "Error - file does not exist: %s\n", path);
+        exit(EXIT_FAILURE);
+    }
+}
+
+// ---------------------------------------------------------------- stats ---
+// reference src/alignments.cpp:237-276 (+ :304-351 for the duplicate marks)
+struct AlignmentTotals {
+    unsigned long long qlen = 0, algseq = 0, plus = 0, minus = 0, plen = 0, mapq = 0,
+                       matches = 0, blocklen = 0;
+    unsigned long long primary = 0, secondary = 0, supplementary = 0, terminal_supp = 0;
+    void add(const GafRecord &r)
+    {
+        qlen += r.qlen;
+        algseq += r.qend - r.qstart;
+        (r.strand == '+' ? plus : minus)++;
+        plen += r.plen;
+        matches += r.matches;
+        blocklen += r.blocklen;
+        mapq += r.mapq;
+    }
+};
+
+// gfalibs gfa_round: two decimals.  `fixed` reproduces the stream state the
+// reference is in when the summary is printed from outputAlignments
+// (validateFiles/test.7.tst: "80.00") as opposed to evalGFA (test.0: "37.5").
+std::string rounded(double v, bool fixed)
+{
+    std::ostringstream os;
+    double r = std::round(v * 100.0) / 100.0;
+    if (fixed) os << std::fixed << std::setprecision(2);
+    os << r;
+    return os.str();
+}
+
+void print_stats(const AlignmentTotals &t, size_t n, bool fixed)
+{
+    auto avg = [&](unsigned long long v) { return rounded((double)v / (double)n, fixed); };
+    std::cout << "+++Alignment summary+++: \n";
+    std::cout << "# alignments: " << n << "\n";
+    std::cout << "Average read length: " << avg(t.qlen) << "\n";
+    std::cout << "Average aligned sequence: " << avg(t.algseq) << "\n";
+    std::cout << "Alignment orientation (+/-): " << t.plus << "("
+              << rounded((double)t.plus / (double)(t.plus + t.minus) * 100, fixed) << "%):"
+              << t.minus << "("
+              << rounded((double)t.minus / (double)(t.plus + t.minus) * 100, fixed) << "%)\n";
+    std::cout << "Average path length: " << avg(t.plen) << "\n";
+    std::cout << "Average alignment quality: " << avg(t.mapq) << "\n";
+    std::cout << "Average matches #: " << avg(t.matches) << "\n";
+    std::cout << "Average block length: " << avg(t.blocklen) << "\n";
+    std::cout << "Primary alignments: " << t.primary << "\n";
+    std::cout << "Secondary alignments: " << t.secondary << "\n";
+    std::cout << "Supplementary alignments: " << t.supplementary << "\n";
+    std::cout << "Terminal supplementary alignments: " << t.terminal_supp << "\n";
+}
+
+// ------------------------------------------------------------ evalPath ---
+// Host restatement of the traceback rows, for PRINTING only: the counters and
+// the per-alignment scores come from the GPU; this renders the B row of the
+// winning orientation (reference include/alignments.h:113-121).
+struct Rows {
+    std::vector<Step> a, b;
+    int score = 0;
+};
+
+Rows traceback_rows(const std::vector<Step> &A, const std::vector<Step> &B)
+{
+    const int n = (int)A.size(), m = (int)B.size();
+    auto eq = [](const Step &x, const Step &y) {
+        return x.id == y.id && x.orientation == y.orientation;
+    };
+    std::vector<int> dp((size_t)(n + 1) * (m + 1), 0);
+    auto at = [&](int i, int j) -> int & { return dp[(size_t)i * (m + 1) + j]; };
+    for (int j = 0; j <= m && j <= n; ++j) at(0, j) = -j;       // src/alignments.cpp:500
+    for (int i = 1; i <= n; ++i)
+        for (int j = 1; j <= m; ++j) {
+            int s = eq(A[i - 1], B[j - 1]) ? 0 : -1;
+            at(i, j) = std::max(at(i - 1, j - 1) + s,
+                                std::max(at(i - 1, j) + (j < m ? -1 : 0), at(i, j - 1) - 1));
+        }
+    Rows r;
+    const Step gap{-1, '0'};
+    int i = n, j = m, taken = 0;
+    while (i != 0 || j != 0) {                                   // :516-550
+        if (i == 0) {
+            r.a.push_back(gap); r.b.push_back(B[j - 1]); --j;
+        } else if (j == 0) {
+            r.a.push_back(A[i - 1]); r.b.push_back(gap); --i;
+        } else {
+            int s = eq(A[i - 1], B[j - 1]) ? 0 : -1;
+            if (at(i, j) == at(i - 1, j - 1) + s) {
+                r.a.push_back(A[i - 1]); r.b.push_back(B[j - 1]);
+                ++taken; --i; --j; r.score += s;
+            } else if (at(i - 1, j) >= at(i, j - 1)) {
+                r.a.push_back(A[i - 1]); r.b.push_back(gap); --i;
+                if (taken > 0) r.score -= 1;
+            } else {
+                r.a.push_back(gap); r.b.push_back(B[j - 1]);
+                ++taken; --j; r.score -= 1;
+            }
+        }
+    }
+    std::reverse(r.a.begin(), r.a.end());
+    std::reverse(r.b.begin(), r.b.end());
+    return r;
+}
+
+std::string b_row(const Rows &r, const Graph &g)   // include/alignments.h:113-121
+{
+    std::string s;
+    for (size_t i = 0; i < r.b.size(); ++i) {
+        const Step &x = r.a[i], &y = r.b[i];
+        if (y.id == -1)
+            s += std::string(g.headers[(size_t)x.id].size() + 1, '-') + ",";
+        else if (x.id != y.id || x.orientation != y.orientation)
+            s += g.headers[(size_t)y.id] + y.orientation + ",";
+        else
+            s += std::string(g.headers[(size_t)y.id].size() + 1, '.') + ",";
+    }
+    return s;
+}
+
+int run_eval_path(const Options &o, const Graph &g, const std::vector<GafRecord> &recs)
+{
+    // src/eval.cpp:203-227: split on ',' / ';', last char = orientation
+    std::vector<Step> path;
+    std::string comp;
+    std::vector<std::string> comps;
+    for (char c : o.path) {
+        if (c == ',' || c == ';') {
+            comps.push_back(comp);
+            comp.clear();
+        } else {
+            comp += c;
+        }
+    }
+    comps.push_back(comp);
+    for (size_t k = 0; k < comps.size(); ++k) {
+        std::string c = comps[k];
+        if (k == 0 && c.empty()) {
+            fprintf(stderr, "Error: cannot handle starting gap. Terminating.\n");
+            return 1;
+        }
+        if (c.empty()) {   // the reference would index an empty string here (UB)
+            fprintf(stderr, "Error: cannot find node (). Terminating.\n");
+            return 1;
+        }
+        char orient = c.back();
+        c.pop_back();
+        auto it = g.ids.find(c);
+        if (it == g.ids.end()) {
+            fprintf(stderr, "Error: cannot find node (%s). Terminating.\n", c.c_str());
+            return 1;
+        }
+        path.push_back({(int32_t)it->second, orient});
+    }
+    if (path.size() > GFAL_MAX_STEPS) {
+        fprintf(stderr, "Error: path longer than %d steps.\n", GFAL_MAX_STEPS);
+        return 1;
+    }
+    const uint32_t uniques = count_uniques(path);
+
+    PackedAlignments packed;
+    for (auto &r : recs) packed.add(r, g);
+    PathScorer scorer;
+    if (!scorer.open(packed, (int32_t)g.headers.size(), o.device)) return 1;
+
+    std::cout << path_string(path, g) << std::endl;                       // :72-73
+    std::vector<int32_t> pst;
+    for (auto &s : path) pst.push_back(pack(s));
+    std::vector<int32_t> off{0, (int32_t)pst.size()};
+    std::vector<uint32_t> bad, good;
+    if (!scorer.score(off, pst, false, bad, good)) return 1;              // :238
+    std::vector<int32_t> fw((size_t)recs.size()), rc((size_t)recs.size());
+    if (scorer.n_aln() > 0) {
+        int err = gfal_scorer_pair_scores(scorer.handle(), pst.data(), (int32_t)pst.size(),
+                                          fw.data(), rc.data());
+        if (err != GFAL_OK) {
+            fprintf(stderr, "Error: scorer: %s (%s)\n", gfal_strerror(err), gfal_last_error());
+            return 1;
+        }
+    }
+    for (size_t k = 0; k < recs.size(); ++k) {                            // :100-102
+        std::vector<Step> B;
+        for (int32_t t = packed.off[k]; t < packed.off[k + 1]; ++t)
+            B.push_back({packed.steps[(size_t)t] >> 1, (packed.steps[(size_t)t] & 1) ? '-' : '+'});
+        const bool show_fw = fw[k] > rc[k];
+        if (!show_fw) {   // include/alignments.h:64-70
+            std::reverse(B.begin(), B.end());
+            for (auto &s : B) s.orientation = (s.orientation == '+') ? '-' : '+';
+        }
+        Rows rows = traceback_rows(path, B);
+        const int32_t best = std::max(fw[k], rc[k]);
+        if (rows.score != best) {
+            fprintf(stderr, "Error: device score %d != rendered score %d for %s\n", best,
+                    rows.score, recs[k].qname.c_str());
+            return 1;
+        }
+        std::cout << b_row(rows, g) << '\t' << recs[k].qname << '\t' << best << std::endl;
+    }
+    const int32_t alt = (int32_t)bad[0] - (int32_t)good[0] - (int32_t)uniques;
+    std::cout << bad[0] << "\t" << good[0] << "\t" << alt << "\t" << path.size() << "\t"
+              << uniques << std::endl;                                     // :241
+    return 0;
+}
+
+// -------------------------------------------------------------- filter ---
+int run_filter(const Options &o, std::vector<GafRecord> &recs, const AlignmentTotals &totals)
+{
+    std::unordered_set<std::string> allowed;      // src/input-gfalign.cpp:65-74
+    {
+        std::ifstream in(o.node_file);
+        std::string line;
+        while (std::getline(in, line)) allowed.insert(line);
+    }
+    std::vector<GafRecord> kept;                   // src/alignments.cpp:459-472
+    std::vector<std::pair<std::string, char>> nodes;
+    for (auto &r : recs) {
+        gaf_path_nodes(r.path, nodes);
+        bool inside = true;
+        for (auto &nd : nodes) inside &= allowed.count(nd.first) != 0;
+        if (inside && (int32_t)nodes.size() >= (int32_t)o.min_nodes) kept.push_back(std::move(r));
+    }
+    recs.swap(kept);
+    if (o.out_file.empty()) return 0;              // src/input-gfalign.cpp:116-117
+    // src/alignments.cpp:286-302: totals are the ones accumulated at load time
+    print_stats(totals, recs.size(), true);
+    std::ofstream out(o.out_file);
+    for (auto &r : recs) out << r.print();
+    return 0;
+}
+
+// ------------------------------------------------------------- evalGFA ---
+int run_eval_gfa(const Options &o, std::vector<GafRecord> &recs, AlignmentTotals totals)
+{
+    if (o.gaf.empty()) return 0;
+    std::stable_sort(recs.begin(), recs.end(),
+                     [](const GafRecord &a, const GafRecord &b) { return a.qname < b.qname; });
+    // src/alignments.cpp:304-351
+    std::string prev;
+    std::vector<const GafRecord *> group;
+    for (size_t k = 0; k < recs.size(); ++k) {
+        group.push_back(&recs[k]);
+        if (recs[k].qname == prev) {
+            ++totals.secondary;
+            if (k + 1 == recs.size() || recs[k + 1].qname != recs[k].qname) {
+                std::vector<const GafRecord *> g2 = group;
+                std::stable_sort(g2.begin(), g2.end(), [](const GafRecord *a, const GafRecord *b) {
+                    return a->qstart < b->qstart;
+                });
+                unsigned pos = 0, count = 0;
+                for (auto *r : g2) {
+                    if (pos != 0 && r->qstart > pos) {
+                        ++totals.supplementary;
+                        ++count;
+                    }
+                    pos = r->qend;
+                }
+                if (g2.size() == 2 && count == 1 && g2[0]->pend + 500 >= g2[0]->plen &&
+                    g2[1]->pstart <= 500) {
+                    ++totals.terminal_supp;
+                    if (o.terminal_alignments) std::cout << g2[0]->print() << g2[1]->print();
+                }
+                group.clear();
+            }
+        } else {
+            ++totals.primary;
+            prev = recs[k].qname;
+        }
+    }
+    print_stats(totals, recs.size(), false);
+    if (o.sort_alignment)
+        for (auto &r : recs) std::cout << r.print();
+    if (!o.out_file.empty()) {
+        fprintf(stderr, "Error: evalGFA -o (RC:i edge tagging + GFA output) is not part of this "
+                        "build.\n");
+        return 1;
+    }
+    return 0;
+}
+
+void print_help()
+{
+    printf("gfalign [command]\n-h for additional help.\n");
+    printf("\nModes:\n");
+    printf("evalGFA\nsearch\nfilter\nevalPath\n");
+    exit(0);
+}
+
+}  // namespace
+
+int main(int argc, char **argv)
+{
+    if (argc == 1) print_help();
+    Options o;
+    const std::string tool = argv[1];
+    if (tool == "evalGFA") o.mode = 1;
+    else if (tool == "search") o.mode = 3;
+    else if (tool == "filter") o.mode = 4;
+    else if (tool == "evalPath") o.mode = 5;
+    else if (tool == "align" || tool == "subgraph") {
+        fprintf(stderr, "mode '%s' is not part of this build (see DESIGN.md).\n", argv[1]);
+        return EXIT_FAILURE;
+    } else if (tool == "-h" || tool == "--help") {
+        print_help();
+    } else if (tool == "-v" || tool == "--version") {
+        printf("gfalign v%s\n", VERSION);
+        return 0;
+    } else {
+        fprintf(stderr, "mode '%s' does not exist. Terminating.\n", argv[1]);   // main.cpp:116
+        return EXIT_FAILURE;
+    }
+
+    static struct option long_options[] = {
+        {"destination", required_argument, 0, 'd'},
+        {"input-sequence", required_argument, 0, 'f'},
+        {"input-alignment", required_argument, 0, 'g'},
+        {"max-steps", required_argument, 0, 'm'},
+        {"node-file", required_argument, 0, 'n'},
+        {"node-list", required_argument, 0, 'n'},
+        {"out-format", required_argument, 0, 'o'},
+        {"source", required_argument, 0, 's'},
+        {"path", required_argument, 0, 'p'},
+        {"threads", required_argument, 0, 'j'},
+        {"return-all-paths", no_argument, &o.return_all_paths, 1},
+        {"graph-statistics", no_argument, &o.stats_flag, 1},
+        {"sort-alignment", no_argument, &o.sort_alignment, 1},
+        {"output-terminal-alignments", no_argument, &o.terminal_alignments, 1},
+        {"min-nodes", required_argument, 0, 1},
+        {"device", required_argument, 0, 2},
+        {"cmd", no_argument, &o.cmd_flag, 1},
+        {"verbose", no_argument, &verbose_flag, 1},
+        {"version", no_argument, 0, 'v'},
+        {"help", no_argument, 0, 'h'},
+        {0, 0, 0, 0}};
+    int c, idx = 0;
+    while ((c = getopt_long(argc, argv, "-:d:f:g:j:m:n:o:p:s:vh", long_options, &idx)) != -1) {
+        switch (c) {
+        case 'd': o.destination = optarg; break;
+        case 'f': require_file(optarg); o.gfa = optarg; break;
+        case 'g': require_file(optarg); o.gaf = optarg; break;
+        case 'm': o.max_steps = (uint32_t)atoi(optarg); break;   // main.cpp:462-464 (atoi)
+        case 'n': require_file(optarg); o.node_file = optarg; break;
+        case 'o': o.out_file = optarg; break;
+        case 'p': o.path = optarg; break;
+        case 's': o.source = optarg; break;
+        case 'j': break;
+        case 1: o.min_nodes = (uint32_t)atoi(optarg); break;
+        case 2: o.device = atoi(optarg); break;
+        case 'v':
+            printf("gfalign v%s\n", VERSION);
+            printf("Giulio Formenti giulio.formenti@gmail.com\n");
+            return 0;
+        case 'h':
+            printf("gfalign %s [options]\nOptions:\n", tool.c_str());
+            printf("-d --destination <string> destination node.\n");
+            printf("-f --input-sequence <filename> sequence input file (GFA1).\n");
+            printf("-g --input-alignment alignment input file (currently supports: GAF).\n");
+            printf("-m --max-steps <int> limit graph exploration.\n");
+            printf("-n --node-file <filename> list of nodes available to the search.\n");
+            printf("-p --path path to evaluate (evalPath).\n");
+            printf("-s --source <string> source node.\n");
+            printf("--return-all-paths return all viable paths as they are discovered, not only "
+                   "better ones (default: false).\n");
+            printf("--min-nodes <int> do not report paths with less than int nodes (default: 0).\n");
+            printf("--device <int> HIP device to score on (default: 0).\n");
+            return 0;
+        default: break;
+        }
+    }
+    if (o.cmd_flag) {   // main.cpp:651-656
+        for (int a = 0; a < argc; ++a) printf("%s ", argv[a]);
+        printf("\n");
+    }
+
+    Graph g;
+    std::string err;
+    if (!o.gfa.empty() && !read_gfa(o.gfa, g, err)) {
+        fprintf(stderr, "Error: %s\n", err.c_str());
+        return EXIT_FAILURE;
+    }
+    std::vector<GafRecord> recs;
+    AlignmentTotals totals;
+    if (!o.gaf.empty()) {
+        if (!read_gaf(o.gaf, recs, err)) {
+            fprintf(stderr, "Error: %s\n", err.c_str());
+            return EXIT_FAILURE;
+        }
+        for (auto &r : recs) totals.add(r);
+    }
+
+    switch (o.mode) {
+    case 1: return run_eval_gfa(o, recs, totals);
+    case 3: {
+        PackedAlignments packed;
+        for (auto &r : recs) packed.add(r, g);
+        if (!g.ids.count(o.source) || !g.ids.count(o.destination)) {
+            // the reference would alias an unknown name to uId 0; refuse instead
+            fprintf(stderr, "Error: source or destination not in graph.\n");
+            return EXIT_FAILURE;
+        }
+        PathScorer scorer;
+        if (!scorer.open(packed, (int32_t)g.headers.size(), o.device)) return EXIT_FAILURE;
+        SearchOptions so;
+        so.node_file = o.node_file;
+        so.source = o.source;
+        so.destination = o.destination;
+        so.max_steps = o.max_steps;
+        so.min_nodes = o.min_nodes;
+        so.return_all_paths = o.return_all_paths != 0;
+        if (const char *k = getenv("GFALIGN_SPECULATE")) so.speculate = (size_t)std::max(1, atoi(k));
+        Search search(g, scorer, so, std::cout);
+        int rc = search.run();
+        if (verbose_flag)
+            fprintf(stderr, "scored %llu candidate paths in %llu batches\n",
+                    (unsigned long long)search.scored_paths(),
+                    (unsigned long long)search.batches());
+        return rc;
+    }
+    case 4: return run_filter(o, recs, totals);
+    case 5: return run_eval_path(o, g, recs);
+    }
+    return EXIT_SUCCESS;
+}

@@ -1,0 +1,342 @@
+// search.h -- host side of `gfalign search` and `gfalign evalPath`.
+//
+// The best-first expansion of reference src/eval.cpp:110-193 stays on the
+// host; every call of evaluatePath (src/eval.cpp:162) goes through the C ABI
+// of include/gfalign_scorer.h.  Scores are pure functions of the candidate
+// path, so the children of the K best queue entries are scored in one batch
+// ahead of time; entries are still popped, extended, enqueued and printed in
+// exactly the reference's order.
+#ifndef GFALIGN_SEARCH_H
+#define GFALIGN_SEARCH_H
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+#include <map>
+#include <memory>
+#include <set>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "gfalign_scorer.h"
+#include "graph_io.h"
+
+namespace gfal {
+
+// reference include/alignments.h:11-21
+struct Step {
+    int32_t id;
+    char orientation;
+};
+
+inline int32_t pack(const Step &s)
+{
+    if (s.orientation == '+') return s.id << 1;
+    if (s.orientation == '-') return (s.id << 1) | 1;
+    return GFAL_STEP_OTHER | (s.id << 1);
+}
+
+// reference include/nodetable.h: name -> {uId, count}; records keep insertion
+// order here (lookups go through `index`), which nothing observable depends on.
+struct NodeTable {
+    struct Record {
+        std::string name;
+        uint32_t uid, count;
+    };
+    std::vector<Record> records;
+    std::unordered_map<std::string, size_t> index;
+    uint32_t node_count = 0;
+
+    bool load(const std::string &file, const Graph &g)   // nodetable.h:16-43
+    {
+        std::ifstream in(file);
+        std::string line;
+        while (std::getline(in, line)) {
+            auto cols = split(line, '\t');
+            uint32_t count = 1;
+            if (cols.size() > 1) {
+                int c = std::atoi(cols[1].c_str());
+                if (c < 1) continue;
+                count = (uint32_t)c;
+            }
+            node_count += count;
+            auto it = g.ids.find(cols[0]);
+            if (it == g.ids.end()) {
+                fprintf(stderr, "Error: node not in graph (pIUd: %s)\n", cols[0].c_str());
+                return false;
+            }
+            insert(cols[0], it->second, count);
+        }
+        return true;
+    }
+    void insert(const std::string &name, uint32_t uid, uint32_t count)
+    {
+        if (index.count(name)) return;   // flat_hash_map::insert keeps the first
+        index[name] = records.size();
+        records.push_back({name, uid, count});
+    }
+    void add(const std::string &name, uint32_t uid, uint32_t count)   // :49-54
+    {
+        if (count < 1) return;
+        insert(name, uid, count);
+        node_count += count;
+    }
+    // nodetable.h:56-67
+    bool hamiltonian(const std::vector<Step> &path) const
+    {
+        if (path.size() + 2 != node_count) return false;
+        std::unordered_map<uint32_t, uint32_t> seen;
+        for (auto &s : path) ++seen[(uint32_t)s.id];
+        for (auto &r : records) {
+            auto it = seen.find(r.uid);
+            if (it == seen.end() || it->second != r.count) return false;
+        }
+        return true;
+    }
+};
+
+inline std::string path_string(const std::vector<Step> &p, const Graph &g)
+{
+    std::string s;   // include/alignments.h:72-80
+    for (size_t i = 0; i < p.size(); ++i) {
+        s += g.headers[(size_t)p[i].id] + p[i].orientation;
+        if (i + 1 < p.size()) s += ',';
+    }
+    return s;
+}
+
+inline uint32_t count_uniques(const std::vector<Step> &p)   // src/eval.cpp:153-160
+{
+    std::vector<int32_t> ids;
+    ids.reserve(p.size());
+    for (auto &s : p) ids.push_back(s.id);
+    std::sort(ids.begin(), ids.end());
+    return (uint32_t)(std::unique(ids.begin(), ids.end()) - ids.begin());
+}
+
+// Alignments as the packed CSR the scorer wants (src/eval.cpp:123 getPaths).
+struct PackedAlignments {
+    std::vector<int32_t> off{0};
+    std::vector<int32_t> steps;
+    void add(const GafRecord &r, const Graph &g)
+    {
+        std::vector<std::pair<std::string, char>> nodes;
+        gaf_path_nodes(r.path, nodes);
+        for (auto &nd : nodes)
+            steps.push_back((int32_t)((g.id_or_zero(nd.first) << 1) | (nd.second == '-')));
+        off.push_back((int32_t)steps.size());
+    }
+    int64_t size() const { return (int64_t)off.size() - 1; }
+};
+
+// Thin RAII wrapper; scoring with zero alignments never touches the device
+// (the loop of src/eval.cpp:80 has no iterations: all counters are zero).
+class PathScorer {
+public:
+    ~PathScorer()
+    {
+        if (h_) gfal_scorer_destroy(h_);
+    }
+    bool open(const PackedAlignments &a, int32_t n_nodes, int device)
+    {
+        n_aln_ = a.size();
+        if (n_aln_ == 0) return true;
+        int rc = gfal_scorer_create(a.off.data(), a.steps.data(), n_aln_, n_nodes, device, &h_);
+        if (rc != GFAL_OK) {
+            fprintf(stderr, "Error: scorer: %s (%s)\n", gfal_strerror(rc), gfal_last_error());
+            return false;
+        }
+        return true;
+    }
+    bool score(const std::vector<int32_t> &off, const std::vector<int32_t> &steps, bool filter,
+               std::vector<uint32_t> &bad, std::vector<uint32_t> &good)
+    {
+        size_t P = off.size() - 1;
+        bad.assign(P, 0);
+        good.assign(P, 0);
+        if (n_aln_ == 0 || P == 0) return true;
+        int rc = gfal_scorer_score(h_, off.data(), steps.data(), (int32_t)P, filter ? 1 : 0,
+                                   bad.data(), good.data(), nullptr);
+        if (rc != GFAL_OK) {
+            fprintf(stderr, "Error: scorer: %s (%s)\n", gfal_strerror(rc), gfal_last_error());
+            return false;
+        }
+        return true;
+    }
+    gfal_scorer *handle() { return h_; }
+    int64_t n_aln() const { return n_aln_; }
+
+private:
+    gfal_scorer *h_ = nullptr;
+    int64_t n_aln_ = 0;
+};
+
+struct SearchOptions {
+    std::string node_file, source, destination;
+    uint32_t max_steps = 100000;   // include/input-gfalign.h:12
+    uint32_t min_nodes = 0;
+    bool return_all_paths = false;
+    size_t speculate = 512;        // queue entries whose children are scored per batch
+};
+
+// reference src/eval.cpp:110-193
+class Search {
+public:
+    Search(const Graph &g, PathScorer &scorer, const SearchOptions &opt, std::ostream &out)
+        : g_(g), scorer_(scorer), opt_(opt), out_(out) {}
+
+    int run()
+    {
+        NodeTable table;
+        if (!table.load(opt_.node_file, g_)) return EXIT_FAILURE;           // :126
+        table.add(opt_.source, g_.id_or_zero(opt_.source), 1);             // :127
+        table.add(opt_.destination, g_.id_or_zero(opt_.destination), 1);   // :128
+        table_ = &table;
+        const uint32_t dest_uid = table.records[table.index.at(opt_.destination)].uid;
+        const uint32_t src_uid = table.records[table.index.at(opt_.source)].uid;
+
+        // per-uid record index for the budget gate (:142-143); -1 = not listed
+        record_of_.assign(g_.headers.size(), -1);
+        for (size_t r = 0; r < table.records.size(); ++r) {
+            // the gate looks the header up by NAME; a record whose name is not
+            // that uid's header (unknown source aliased to uid 0) never matches
+            if (table.records[r].uid < g_.headers.size() &&
+                g_.headers[table.records[r].uid] == table.records[r].name)
+                record_of_[table.records[r].uid] = (int)r;
+        }
+
+        auto first = std::make_unique<Entry>();
+        first->path.push_back({(int32_t)src_uid, '0'});                     // :130
+        first->budget.resize(table.records.size());
+        for (size_t r = 0; r < table.records.size(); ++r) first->budget[r] = table.records[r].count;
+        queue_.emplace(Key{0, seq_++}, std::move(first));                   // :132
+
+        uint64_t path_counter = 0;
+        uint32_t steps = 0, best_uniques = 0;
+        int32_t best_alt = INT32_MAX;
+        while (!queue_.empty() && steps < opt_.max_steps) {                 // :134
+            if (!queue_.begin()->second->expanded && !expand_front()) return EXIT_FAILURE;
+            std::unique_ptr<Entry> u = std::move(queue_.begin()->second);   // :135
+            queue_.erase(queue_.begin());
+            for (Child &c : u->children) {                                  // :136-185
+                const int32_t alt =
+                    (int32_t)c.bad - (int32_t)c.good - (int32_t)c.uniques;  // :163
+                if ((uint32_t)c.path.back().id != dest_uid) {               // :165-169
+                    auto e = std::make_unique<Entry>();
+                    e->budget = u->budget;
+                    --e->budget[(size_t)c.record];
+                    e->path = std::move(c.path);
+                    queue_.emplace(Key{alt, seq_++}, std::move(e));
+                } else {                                                    // :170-184
+                    ++path_counter;
+                    const bool ham = table.hamiltonian(c.path);
+                    bool print = false;
+                    if (c.uniques >= opt_.min_nodes &&
+                        (best_uniques < c.uniques ||
+                         (best_uniques == c.uniques && best_alt > alt))) {
+                        best_alt = alt;
+                        best_uniques = c.uniques;
+                        print = true;
+                    }
+                    if (opt_.return_all_paths || print)
+                        out_ << path_counter << '\t' << c.bad << '\t' << c.good << '\t' << alt
+                             << '\t' << c.path.size() << '\t' << c.uniques << '\t'
+                             << (ham ? 'T' : 'F') << '\t' << path_string(c.path, g_)
+                             << std::endl;
+                }
+            }
+            ++steps;                                                        // :187
+        }
+        if (steps >= opt_.max_steps)                                        // :190-191
+            out_ << "Reached maximum number of steps (" << steps << ")" << std::endl;
+        return EXIT_SUCCESS;
+    }
+
+    uint64_t scored_paths() const { return scored_; }
+    uint64_t batches() const { return batches_; }
+
+private:
+    struct Child {
+        std::vector<Step> path;
+        int record = -1;          // node-table record of the node stepped onto
+        uint32_t uniques = 0, bad = 0, good = 0;
+    };
+    struct Entry {
+        std::vector<Step> path;
+        std::vector<uint32_t> budget;   // per node-table record (include/alignments.h:26)
+        std::vector<Child> children;
+        bool expanded = false;
+    };
+    struct Key {
+        int32_t alt;
+        uint64_t seq;   // FIFO among equal keys
+        bool operator<(const Key &o) const
+        {
+            return alt != o.alt ? alt < o.alt : seq < o.seq;
+        }
+    };
+
+    // Extensions of one queue entry, in adjacency order (:136-151).
+    void make_children(Entry &e) const
+    {
+        const Step last = e.path.back();
+        for (const Edge &v : g_.adjacency[(size_t)last.id]) {
+            if (last.orientation != '0' && last.orientation != v.from_orient) continue;   // :137
+            const int rec = record_of_[v.to];
+            if (rec < 0 || e.budget[(size_t)rec] == 0) continue;                          // :142-143
+            Child c;
+            c.path = e.path;
+            if (c.path.back().orientation == '0') c.path.back().orientation = v.from_orient;
+            c.path.push_back({(int32_t)v.to, v.to_orient});
+            c.record = rec;
+            c.uniques = count_uniques(c.path);
+            e.children.push_back(std::move(c));
+        }
+    }
+
+    // Score the children of the front entry together with those of the next
+    // best entries that have not been expanded yet (speculation; see header).
+    bool expand_front()
+    {
+        std::vector<Entry *> todo;
+        for (auto it = queue_.begin(); it != queue_.end() && todo.size() < opt_.speculate; ++it)
+            if (!it->second->expanded) todo.push_back(it->second.get());
+        std::vector<int32_t> off{0}, steps;
+        for (Entry *e : todo) {
+            make_children(*e);
+            for (Child &c : e->children) {
+                for (const Step &s : c.path) steps.push_back(pack(s));
+                off.push_back((int32_t)steps.size());
+            }
+        }
+        std::vector<uint32_t> bad, good;
+        if (!scorer_.score(off, steps, true, bad, good)) return false;   // :162
+        size_t k = 0;
+        for (Entry *e : todo) {
+            for (Child &c : e->children) {
+                c.bad = bad[k];
+                c.good = good[k];
+                ++k;
+            }
+            e->expanded = true;
+        }
+        scored_ += k;
+        ++batches_;
+        return true;
+    }
+
+    const Graph &g_;
+    PathScorer &scorer_;
+    SearchOptions opt_;
+    std::ostream &out_;
+    const NodeTable *table_ = nullptr;
+    std::vector<int> record_of_;
+    std::map<Key, std::unique_ptr<Entry>> queue_;
+    uint64_t seq_ = 0, scored_ = 0, batches_ = 0;
+};
+
+}  // namespace gfal
+#endif

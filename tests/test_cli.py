@@ -1,0 +1,157 @@
+"""The `gfalign` command line (host driver around the C ABI).
+
+CPU part: everything that does not score alignments -- the reference's own
+golden tests test.6 (search without -g) and test.7 (filter), option handling,
+the best-first order against the Python search oracle.
+GPU part: search with alignments, evalPath (C.2), and
+a synthetic tangle against the search oracle; speculation must not change a
+byte of stdout.
+"""
+import os
+import subprocess
+
+import pytest
+
+from gfalign_amd import build as gbuild
+from gfalign_amd import synth
+from helpers import REF_FILES, load_appendix_c
+from oracle import search_oracle
+
+
+@pytest.fixture(scope="module")
+def cli():
+    path = gbuild.build_cli()
+    assert path and os.path.exists(path)
+    return path
+
+
+def run(cli, args, cwd=None, env=None):
+    e = dict(os.environ)
+    if env:
+        e.update(env)
+    p = subprocess.run([cli] + args, cwd=cwd, env=e, capture_output=True, text=True, timeout=600)
+    return p.returncode, p.stdout, p.stderr
+
+
+def tst(name):
+    with open(os.path.join(REF_FILES, name)) as f:
+        lines = f.read().split("\n")
+    return lines[0].split()[1:], "\n".join(lines[2:])
+
+
+def test_reference_test6_search_without_alignments(cli, tmp_path):
+    args, expected = tst("test.6.tst")
+    args = [a.replace("testFiles/", REF_FILES + "/") for a in args]
+    rc, out, _ = run(cli, args)
+    assert rc == 0 and out == expected
+
+
+def test_reference_test7_filter(cli, tmp_path):
+    args, expected = tst("test.7.tst")
+    args = [a.replace("testFiles/", REF_FILES + "/") for a in args]
+    rc, out, _ = run(cli, args, cwd=str(tmp_path))     # writes ./gaf like the reference
+    assert rc == 0 and out == expected
+    with open(os.path.join(REF_FILES, "test.7.output.gaf")) as f:
+        assert (tmp_path / "gaf").read_text() == f.read()
+
+
+def test_filter_min_nodes(cli, tmp_path):
+    rc, out, _ = run(cli, ["filter", "-g", REF_FILES + "/random3.gaf", "-n",
+                           REF_FILES + "/random3.filter_nodelist.ls", "-o", "x.gaf",
+                           "--min-nodes", "3"], cwd=str(tmp_path))
+    assert rc == 0
+    rows = (tmp_path / "x.gaf").read_text().splitlines()
+    assert [r.split("\t")[5] for r in rows] == [">1>2>3>4", ">4>3>2>1"]
+    assert "# alignments: 2" in out
+
+
+def test_step_cap_message_and_atoi(cli):
+    base = ["search", "-f", REF_FILES + "/random3.gfa", "-n",
+            REF_FILES + "/random3.search_nodelist.tsv", "-s", "1", "-d", "4"]
+    rc, out, _ = run(cli, base + ["-m", "2"])
+    assert out.splitlines()[-1] == "Reached maximum number of steps (2)"
+    # reference parses -m with atoi: "1e9" means 1 step (src/main.cpp:462-464)
+    rc, out, _ = run(cli, base + ["-m", "1e9"])
+    assert out.splitlines()[-1] == "Reached maximum number of steps (1)"
+
+
+def test_unknown_mode_and_missing_file(cli):
+    rc, _, err = run(cli, ["frobnicate"])
+    assert rc != 0 and "mode 'frobnicate' does not exist. Terminating." in err
+    rc, _, err = run(cli, ["search", "-f", "/nonexistent.gfa"])
+    assert rc != 0
+
+
+def _write_tangle(t, d):
+    t.write_gfa(os.path.join(d, "g.gfa"))
+    t.write_nodelist(os.path.join(d, "nodes.tsv"))
+    t.write_gaf(os.path.join(d, "a.gaf"))
+
+
+def test_search_order_matches_oracle_without_alignments(cli, tmp_path):
+    """Best-first order, budgets, uniques, Hamiltonian flag, printing rule."""
+    t = synth.Tangle(V=14, n_T=12, N=10, P=1, seed=21)
+    _write_tangle(t, str(tmp_path))
+    args = dict(gfa=str(tmp_path / "g.gfa"), node_file=str(tmp_path / "nodes.tsv"),
+                source="utig4-0", destination="utig4-13", max_steps=400)
+    for extra_cli, extra in ((["--return-all-paths"], dict(return_all_paths=True)),
+                             (["--min-nodes", "5"], dict(min_nodes=5)), ([], {})):
+        exp = search_oracle.search(**args, **extra)
+        rc, out, _ = run(cli, ["search", "-f", args["gfa"], "-n", args["node_file"], "-s",
+                               args["source"], "-d", args["destination"], "-m", "400"] + extra_cli)
+        assert rc == 0 and out.splitlines() == exp
+        assert len(exp) >= (2 if extra.get("return_all_paths") else 1)
+        if not extra:
+            assert exp[0].split("\t")[6] == "T"      # a Hamiltonian path is flagged
+
+
+def test_search_needs_a_gpu_when_there_are_alignments(cli):
+    from gfalign_amd import scorer
+    if scorer.device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    rc, out, err = run(cli, ["search", "-f", REF_FILES + "/random3.gfa", "-g",
+                             REF_FILES + "/random3.gaf", "-n",
+                             REF_FILES + "/random3.search_nodelist.tsv", "-s", "1", "-d", "4"])
+    assert rc != 0 and "no usable HIP device" in err and out == ""
+
+
+# ---------------------------------------------------------------- GPU ----
+
+@pytest.mark.gpu
+def test_search_with_alignments_appendix_c1(cli, gpu):
+    gold = load_appendix_c()["search_with_gaf"]
+    base = ["search", "-f", REF_FILES + "/random3.gfa", "-g", REF_FILES + "/random3.gaf",
+            "-n", REF_FILES + "/random3.search_nodelist.tsv", "-s", "1", "-d", "4"]
+    rc, out, err = run(cli, base)
+    assert rc == 0, err
+    assert out.splitlines() == gold["stdout"]
+    rc, out, _ = run(cli, base + ["--return-all-paths"])
+    assert out.splitlines() == gold["stdout"] + [gold["return_all_paths_extra_row"]]
+
+
+@pytest.mark.gpu
+def test_eval_path_appendix_c2(cli, gpu):
+    gold = load_appendix_c()["eval_path"]
+    rc, out, err = run(cli, ["evalPath", "-f", REF_FILES + "/random3.gfa", "-g",
+                             REF_FILES + "/random3.gaf", "-p", gold["path"]])
+    assert rc == 0, err
+    assert out.splitlines() == gold["stdout"]
+
+
+@pytest.mark.gpu
+def test_search_on_a_synthetic_tangle_matches_oracle(cli, gpu, tmp_path):
+    t = synth.Tangle(V=30, n_T=24, N=400, P=1, seed=22)
+    _write_tangle(t, str(tmp_path))
+    gfa, nodes, gaf = (str(tmp_path / n) for n in ("g.gfa", "nodes.tsv", "a.gaf"))
+    exp = search_oracle.search(gfa, nodes, "utig4-0", "utig4-29", gaf=gaf, max_steps=150,
+                               return_all_paths=True)
+    base = ["search", "-f", gfa, "-g", gaf, "-n", nodes, "-s", "utig4-0", "-d", "utig4-29",
+            "-m", "150", "--return-all-paths"]
+    outs = []
+    for spec in ("1", "7", "512"):
+        rc, out, err = run(cli, base, env={"GFALIGN_SPECULATE": spec})
+        assert rc == 0, err
+        outs.append(out)
+    assert outs[0] == outs[1] == outs[2]          # batching never changes the output
+    assert outs[0].splitlines() == exp
+    assert any(int(r.split("\t")[2]) > 0 for r in exp[:-1])   # non-zero good counters
