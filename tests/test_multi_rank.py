@@ -1,0 +1,75 @@
+"""CPU, world_size 2 over gloo: the multi-GPU contract of SURVEY.md 8(e).
+
+Each rank takes its shard of the alignments (gfalign_amd.shard), produces the
+per-path counters for the whole candidate batch, and the [3P] integer counters
+are summed with one all-reduce.  On the GPU box the per-rank scorer is the HIP
+path and the backend is RCCL; here the oracle stands in for the scorer so that
+the sharding and the collective can be checked without a GPU.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle
+from gfalign_amd import shard, synth
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _rank_main(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = synth.make("smoke")
+    off, st = shard.take_shard(t.aln_off, t.aln_steps, rank, world)
+    bad, good, una = oracle.evaluate_paths(off, st, t.path_off, t.path_steps, True)
+    counts = torch.from_numpy(np.concatenate([bad, good, una]).astype(np.int32))
+    shard.all_reduce_counts(counts)
+    np.save(os.path.join(out_dir, "rank%d.npy" % rank), counts.numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_counters_equal_unsharded(tmp_path, world):
+    port = _free_port()
+    mp.spawn(_rank_main, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    t = synth.make("smoke")
+    exp = np.concatenate(oracle.evaluate_paths(t.aln_off, t.aln_steps, t.path_off,
+                                               t.path_steps, True)).astype(np.int32)
+    for r in range(world):
+        got = np.load(tmp_path / ("rank%d.npy" % r))
+        assert np.array_equal(got, exp), r
+
+
+def test_shard_bounds_cover_everything_once():
+    t = synth.make("config2")
+    for world in (1, 2, 3, 8):
+        b = shard.shard_bounds(t.aln_off, world)
+        assert b[0] == 0 and b[-1] == t.N and np.all(np.diff(b) >= 0)
+        sizes = [int(t.aln_off[b[r + 1]] - t.aln_off[b[r]]) for r in range(world)]
+        assert sum(sizes) == t.S
+        assert max(sizes) - min(sizes) <= 64          # balanced by step count
+        total = 0
+        for r in range(world):
+            off, st = shard.take_shard(t.aln_off, t.aln_steps, r, world)
+            assert off[0] == 0 and off[-1] == len(st)
+            total += len(off) - 1
+        assert total == t.N
+
+
+def test_more_ranks_than_alignments():
+    off = np.array([0, 2, 5], np.int32)
+    st = np.arange(5, dtype=np.int32)
+    seen = 0
+    for r in range(4):
+        o, s = shard.take_shard(off, st, r, 4)
+        seen += len(o) - 1
+    assert seen == 2
