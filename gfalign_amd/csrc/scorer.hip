@@ -38,17 +38,21 @@
 namespace {
 
 constexpr int WAVE = 64;
-constexpr int SCAN_THREADS = 768;
+constexpr int SCAN_THREADS = 1024;
 constexpr int SCAN_WAVES = SCAN_THREADS / WAVE;
 constexpr int MAX_REG_M = 16;          // alignments up to this length live in VGPRs
 constexpr int MAX_TILE = 32;           // one bit per tile path in the node masks
 constexpr int LDS_BUDGET = 80 * 1024;  // two workgroups per CU (160 KiB LDS)
 constexpr int DP_THREADS = 64;
-constexpr int DP_BLOCKS = 512;
+constexpr int DP_BLOCKS = 512;        // row-scratch kernels (k_dp_long, k_pairs)
+constexpr int DP_REG_BLOCKS = 4096;   // register-row kernels: 4 waves per SIMD
 
-constexpr uint32_t ENT_NONE = 0xFFFFu;     // table / chain: no occurrence
+// Chain entries (first[] / next[]): position | ENT_NEG.  The two terminal
+// values decode to positions 1023 / 1022, which no window test accepts.
+constexpr uint32_t ENT_NONE = 0xFFFFu;     // no (further) occurrence
+constexpr uint32_t ENT_PRESENT = 0xFFFEu;  // node is on the path, but only as
+                                           // steps that equal nothing
 constexpr uint32_t ENT_POS = 0x03FFu;      // position in the path (0..999)
-constexpr uint32_t ENT_NOMATCH = 0x4000u;  // step there equals nothing
 constexpr uint32_t ENT_NEG = 0x8000u;      // step there is '-'
 constexpr uint32_t STEP_NOMATCH = 0xFFFEu; // path step that equals nothing
 constexpr uint32_t STEP_INVALID = 0xFFFFu; // padding lane of an item
@@ -170,16 +174,22 @@ __global__ __launch_bounds__(WAVE) void k_prep(
     }
 
     // Occurrence chains in increasing position order: walk the path backwards.
+    // Steps that equal nothing (STEP_NOMATCH) are left out of the chains; a
+    // node that only has such steps gets ENT_PRESENT (it still passes the
+    // filter).  Bit 15 of lids[] marks the last occurrence of each node.
     if (lane == 0) {
         for (int i = n - 1; i >= 0; --i) {
-            uint32_t lid = lids[i];
+            const uint32_t lid = lids[i];
             if (lid == ENT_NONE) continue;
-            uint32_t code = step[i];
-            uint32_t ent = (uint32_t)i;
-            if (code == STEP_NOMATCH) ent |= ENT_NOMATCH;
-            else if (code & 1u) ent |= ENT_NEG;
-            next[i] = first[lid];
-            first[lid] = (uint16_t)ent;
+            const uint32_t head = first[lid];
+            if (head == ENT_NONE) lids[i] = (uint16_t)(lid | 0x8000u);
+            const uint32_t code = step[i];
+            if (code == STEP_NOMATCH) {
+                if (head == ENT_NONE) first[lid] = (uint16_t)ENT_PRESENT;
+                continue;
+            }
+            next[i] = (uint16_t)(head == ENT_PRESENT ? ENT_NONE : head);
+            first[lid] = (uint16_t)((uint32_t)i | ((code & 1u) ? ENT_NEG : 0u));
         }
         img[L.len_at()] = (uint16_t)n;
         img[L.len_at() + 1] = 0;
@@ -188,13 +198,12 @@ __global__ __launch_bounds__(WAVE) void k_prep(
 
     // unaligned (src/eval.cpp:83-88) = steps of all alignments whose node is
     // not on the path = total - sum over the distinct path nodes of how many
-    // alignment steps carry them.  A node's last occurrence (chain tail)
-    // stands for it.
+    // alignment steps carry them.
     uint32_t covered = 0;
     if (filter) {
         for (int i = lane; i < n; i += WAVE) {
-            uint32_t lid = lids[i];
-            if (lid != ENT_NONE && next[i] == ENT_NONE) covered += node_hist[lid];
+            const uint32_t lid = lids[i];
+            if (lid != ENT_NONE && (lid & 0x8000u)) covered += node_hist[lid & 0x7FFFu];
         }
     }
 
@@ -300,82 +309,112 @@ __device__ __forceinline__ bool tail_equals(const uint16_t *__restrict__ bp, int
     return eq;
 }
 
-// Wave vote without the bool -> int round trip of __any().
+// Wave votes as 64-bit lane masks (SGPR pairs): most of the per-(wave, path)
+// bookkeeping below is scalar mask arithmetic, not per-lane code.
+using lanemask = unsigned long long;
+#define WAVE_MASK(pred) (__builtin_amdgcn_ballot_w64(pred))
 #define WAVE_ANY(pred) (__builtin_amdgcn_ballot_w64(pred) != 0ull)
 
+// Per-(wave, tile path) counters: lane p of `packed` holds good | bad << 16 for
+// tile path p; flushed into the 32-bit lanes before 16 bits can overflow.
+struct WaveCounts {
+    uint32_t packed = 0, good = 0, bad = 0;
+    int items = 0;
+    __device__ __forceinline__ void add(int p, int lane, lanemask good_m, lanemask bad_m)
+    {
+        const uint32_t inc = (uint32_t)__popcll(good_m) | ((uint32_t)__popcll(bad_m) << 16);
+        packed += (lane == p) ? inc : 0u;
+    }
+    __device__ __forceinline__ void flush()
+    {
+        good += packed & 0xFFFFu;
+        bad += packed >> 16;
+        packed = 0;
+        items = 0;
+    }
+    __device__ __forceinline__ void item_done()
+    {
+        if (++items == 1000) flush();   // 64 per item and field
+    }
+};
+
 // Occurrence-chain search (DESIGN.md "k_scan"): is B a contiguous subpath of
-// the path, or of its reverse complement?  `e` = chain head for B[0]'s node.
-// Both directions are forward scans: the image holds the path's steps and,
-// behind them, the steps of its reverse complement.  The body is branch-free
-// (selects only); the single branch is the wave-level loop test.
+// the path, or of its reverse complement?  `e` = chain head for B[0]'s node
+// (ENT_NONE on lanes that take no part).  Both directions are forward scans:
+// the image holds the path's steps and, nm entries further, the steps of its
+// reverse complement.  Requires M <= n.  Branch-free body; the only branch is
+// the wave-level loop test.  Returns the lanes whose alignment was found.
 template <int M>
-__device__ __forceinline__ bool subpath_search(const uint32_t (&b)[M], uint32_t e,
-                                               const uint16_t *next,
-                                               const uint16_t *stepbase, int nm, int n)
+__device__ __forceinline__ lanemask subpath_search(const uint32_t (&b)[M], uint32_t e,
+                                                   const uint16_t *next,
+                                                   const uint16_t *stepbase, int nm, int n)
 {
-    bool found = false;
+    lanemask found = 0;
     const uint32_t o0 = b[0] & 1u;
-    const uint32_t rc_origin = (uint32_t)(nm + n - 1);
-    do {
-        const bool act = e != ENT_NONE;
+    const uint32_t last_start = (uint32_t)(n - M);
+    const uint32_t n1 = (uint32_t)(n - 1);
+    const uint32_t next_cap = (uint32_t)(nm - 1);
+    while (true) {
         const uint32_t pos = e & ENT_POS;
-        // dir 0: the path step at pos equals b0 -> B may start here.
-        // dir 1: it is b0's complement -> rc(B) may end here, i.e. B may
-        //        start at n-1-pos of the reverse-complemented path.
-        const bool dir = (((e >> 15) ^ o0) & 1u) != 0u;
-        const bool room = dir ? (pos >= (uint32_t)(M - 1)) : ((int)pos + M <= n);
-        // ENT_NONE has the ENT_NOMATCH bit set, so dead lanes never fit
-        const bool fits = room && (e & ENT_NOMATCH) == 0u;
-        // lanes whose window does not fit re-read stepbase[0..M) (in range)
-        const uint32_t at = fits ? (dir ? rc_origin - pos : pos) : 0u;
+        // dir 0: the path step at pos equals b0 -> B may start there.
+        // dir 1: it is b0's complement -> B may start at n-1-pos of rc(path).
+        const uint32_t dir = (e >> 15) ^ o0;
+        const uint32_t start = dir ? n1 - pos : pos;
+        // terminal entries decode to pos 1023/1022: start > n - M either way
+        const bool fits = start <= last_start;
+        const uint32_t at = fits ? dir * (uint32_t)nm + start : 0u;   // else stepbase[0..M)
         const uint16_t *w = stepbase + at;
-        const uint32_t nx = next[act ? pos : 0u];
+        const uint32_t nx = next[min(pos, next_cap)];
         bool ok = fits;
 #pragma unroll
         for (int t = 1; t < M; ++t) ok &= (uint32_t)w[t] == b[t];
-        found |= ok;
-        e = (found || !act) ? ENT_NONE : nx;
-    } while (WAVE_ANY(e != ENT_NONE));
+        found |= WAVE_MASK(ok);
+        const bool more = e < ENT_PRESENT && !ok;
+        e = more ? nx : ENT_NONE;
+        if (!WAVE_ANY(e < ENT_PRESENT)) break;
+    }
     return found;
 }
 
-__device__ __forceinline__ bool subpath_search_long(const uint16_t *__restrict__ bp, int M,
-                                                    uint32_t b0, uint32_t e,
-                                                    const uint16_t *next,
-                                                    const uint16_t *stepbase, int nm,
-                                                    int n)
+__device__ __forceinline__ lanemask subpath_search_long(const uint16_t *__restrict__ bp,
+                                                        int M, uint32_t b0, uint32_t e,
+                                                        const uint16_t *next,
+                                                        const uint16_t *stepbase, int nm,
+                                                        int n)
 {
-    bool found = false;
+    lanemask found = 0;
     const uint32_t o0 = b0 & 1u;
-    const uint32_t rc_origin = (uint32_t)(nm + n - 1);
-    do {
-        const bool act = e != ENT_NONE;
+    const uint32_t last_start = (uint32_t)(n - M);
+    const uint32_t n1 = (uint32_t)(n - 1);
+    const uint32_t next_cap = (uint32_t)(nm - 1);
+    while (true) {
         const uint32_t pos = e & ENT_POS;
-        const bool dir = (((e >> 15) ^ o0) & 1u) != 0u;
-        const bool room = dir ? ((int)pos >= M - 1) : ((int)pos + M <= n);
-        const bool fits = room && (e & ENT_NOMATCH) == 0u;
-        const uint32_t at = fits ? (dir ? rc_origin - pos : pos) : 0u;
+        const uint32_t dir = (e >> 15) ^ o0;
+        const uint32_t start = dir ? n1 - pos : pos;
+        const bool fits = start <= last_start;
+        const uint32_t at = fits ? dir * (uint32_t)nm + start : 0u;
         const uint16_t *w = stepbase + at;
-        const uint32_t nx = next[act ? pos : 0u];
+        const uint32_t nx = next[min(pos, next_cap)];
         bool ok = fits;
         // wave-uniform trip count; a lane that does not fit compares against
         // stepbase[0] throughout (in range) and stays false
         const int lim = WAVE_ANY(fits) ? M : 1;
         for (int t = 1; t < lim; ++t)
             ok &= (uint32_t)w[fits ? t : 0] == (uint32_t)bp[t * WAVE];
-        found |= ok;
-        e = (found || !act) ? ENT_NONE : nx;
-    } while (WAVE_ANY(e != ENT_NONE));
+        found |= WAVE_MASK(ok);
+        const bool more = e < ENT_PRESENT && !ok;
+        e = more ? nx : ENT_NONE;
+        if (!WAVE_ANY(e < ENT_PRESENT)) break;
+    }
     return found;
 }
 
-// One item against the tile.  STEPS_IN_REGS: M is the template constant and
-// b[] holds the steps; otherwise M is `m_long` and steps are read through bp.
+// One item against the tile: M is the template constant and b[] holds the
+// steps of the wave's 64 alignments.
 template <int M>
 __device__ __forceinline__ void scan_item(const ScanArgs &a, const TileView &tv,
                                           const uint16_t *__restrict__ bp, int lane,
-                                          uint32_t slot, uint32_t &cnt_good,
-                                          uint32_t &cnt_bad)
+                                          uint32_t slot, WaveCounts &wc)
 {
     uint32_t b[M];
 #pragma unroll
@@ -392,73 +431,72 @@ __device__ __forceinline__ void scan_item(const ScanArgs &a, const TileView &tv,
 #pragma unroll
         for (int t = 0; t < M; ++t) pass &= tv.nodemask[b[t] >> 1];
     }
+    const uint32_t node0 = b[0] >> 1;
     // positions of the path's first step inside B, refreshed when a0 changes
     uint32_t cached_a0 = 0xFFFFFFFFu, a0_fw = 0, a0_rc = 0;
 
     for (int p = 0; p < tv.tile_paths; ++p) {
-        const bool in = (pass >> p) & 1u;
-        if (!WAVE_ANY(in)) continue;
+        const lanemask in_m = WAVE_MASK(((pass >> p) & 1u) != 0u);
+        if (in_m == 0) continue;
         const int n = __builtin_amdgcn_readlane(tv.hdr_n, p);
-        const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)tv.hdr_a0, p);
+        if (M > n) {                      // src/alignments.cpp:500 row-0 bound:
+            wc.add(p, lane, in_m, 0);           // longer than the path -> good
+            continue;
+        }
         const uint16_t *img = tv.lds + p * a.L.total;
         const uint16_t *stepbase = img + a.L.step_at();
-
-        uint32_t e = in ? (uint32_t)img[a.L.first_at() + (b[0] >> 1)] : ENT_NONE;
-        const bool found =
+        const uint32_t head = img[a.L.first_at() + node0];
+        const uint32_t e = ((pass >> p) & 1u) ? head : ENT_NONE;
+        const lanemask found_m =
             subpath_search<M>(b, e, img + a.L.next_at(), stepbase, a.L.nm, n);
-        bool good = found;
-        bool bad = false;
-        const bool open = in && !found;
-        if (WAVE_ANY(open)) {
-            if (M > n) {                  // src/alignments.cpp:500 row-0 bound
-                good |= open;
-            } else {
-                // B is not a subpath and m <= n: the traceback stays free only
-                // if a proper suffix of B (or of rc(B)) equals a prefix of the
-                // path ("start-overhang").  Exact test; survivors go to k_dp.
-                if (a0 != cached_a0) {
-                    cached_a0 = a0;
-                    a0_fw = 0;
-                    a0_rc = 0;
+        const lanemask open_m = in_m & ~found_m;
+        lanemask bad_m = 0;
+        if (open_m != 0) {
+            // B is not a subpath and m <= n: the traceback stays free only if a
+            // proper suffix of B (or of rc(B)) equals a prefix of the path
+            // ("start-overhang").  Exact test; survivors go to the DP kernels.
+            const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)tv.hdr_a0, p);
+            if (a0 != cached_a0) {
+                cached_a0 = a0;
+                a0_fw = 0;
+                a0_rc = 0;
 #pragma unroll
-                    for (int t = 1; t < M; ++t) a0_fw |= (b[t] == a0) ? (1u << t) : 0u;
+                for (int t = 1; t < M; ++t) a0_fw |= (b[t] == a0) ? (1u << t) : 0u;
 #pragma unroll
-                    for (int t = 0; t < M - 1; ++t)
-                        a0_rc |= ((b[t] ^ 1u) == a0) ? (1u << t) : 0u;
-                }
+                for (int t = 0; t < M - 1; ++t)
+                    a0_rc |= ((b[t] ^ 1u) == a0) ? (1u << t) : 0u;
+            }
+            const lanemask maybe_m = open_m & WAVE_MASK((a0_fw | a0_rc) != 0u);
+            lanemask cand_m = 0;
+            if (maybe_m != 0) {
+                const bool open = (open_m >> lane) & 1ull;
                 bool cand_fw = false, cand_rc = false;
-                if (WAVE_ANY(open && (a0_fw | a0_rc) != 0u)) {
 #pragma unroll
-                    for (int t = 1; t < M; ++t) {      // B[t..M) == path[0..M-t) ?
-                        const bool live = open && ((a0_fw >> t) & 1u);
-                        if (WAVE_ANY(live))
-                            cand_fw |= tail_equals(bp, t, 1, M - t, 0u, stepbase, live);
-                    }
-#pragma unroll
-                    for (int t = 0; t < M - 1; ++t) {  // rc(B)[M-1-t..M) == path[0..t+1) ?
-                        const bool live = open && ((a0_rc >> t) & 1u);
-                        if (WAVE_ANY(live))
-                            cand_rc |= tail_equals(bp, t, -1, t + 1, 1u, stepbase, live);
-                    }
+                for (int t = 1; t < M; ++t) {      // B[t..M) == path[0..M-t) ?
+                    const bool live = open && ((a0_fw >> t) & 1u);
+                    if (WAVE_ANY(live))
+                        cand_fw |= tail_equals(bp, t, 1, M - t, 0u, stepbase, live);
                 }
-                bad = open && !(cand_fw || cand_rc);
+#pragma unroll
+                for (int t = 0; t < M - 1; ++t) {  // rc(B)[M-1-t..M) == path[0..t+1) ?
+                    const bool live = open && ((a0_rc >> t) & 1u);
+                    if (WAVE_ANY(live))
+                        cand_rc |= tail_equals(bp, t, -1, t + 1, 1u, stepbase, live);
+                }
+                cand_m = WAVE_MASK(cand_fw || cand_rc);
                 push_pairs(a, cand_fw, cand_rc, lane, (uint32_t)(tv.path0 + p), slot, M);
             }
+            bad_m = open_m & ~cand_m;
         }
-        const uint32_t g = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(good));
-        const uint32_t d = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(bad));
-        if (lane == p) {
-            cnt_good += g;
-            cnt_bad += d;
-        }
+        wc.add(p, lane, found_m, bad_m);
     }
+    wc.item_done();
 }
 
 // Same decision for alignments too long for registers.
 __device__ __forceinline__ void scan_item_long(const ScanArgs &a, const TileView &tv,
                                                const uint16_t *__restrict__ bp, int M,
-                                               int lane, uint32_t slot,
-                                               uint32_t &cnt_good, uint32_t &cnt_bad)
+                                               int lane, uint32_t slot, WaveCounts &wc)
 {
     const uint32_t first_step = bp[0];
     const bool valid = first_step != STEP_INVALID;
@@ -471,46 +509,43 @@ __device__ __forceinline__ void scan_item_long(const ScanArgs &a, const TileView
         }
     }
     for (int p = 0; p < tv.tile_paths; ++p) {
-        const bool in = (pass >> p) & 1u;
-        if (!WAVE_ANY(in)) continue;
+        const lanemask in_m = WAVE_MASK(((pass >> p) & 1u) != 0u);
+        if (in_m == 0) continue;
         const int n = __builtin_amdgcn_readlane(tv.hdr_n, p);
+        if (M > n) {
+            wc.add(p, lane, in_m, 0);
+            continue;
+        }
         const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)tv.hdr_a0, p);
         const uint16_t *img = tv.lds + p * a.L.total;
         const uint16_t *stepbase = img + a.L.step_at();
-        uint32_t e = in ? (uint32_t)img[a.L.first_at() + (b0 >> 1)] : ENT_NONE;
-        const bool found = subpath_search_long(bp, M, b0, e, img + a.L.next_at(),
-                                               stepbase, a.L.nm, n);
-        bool good = found;
-        bool bad = false;
-        const bool open = in && !found;
-        if (WAVE_ANY(open)) {
-            if (M > n) {
-                good |= open;
-            } else {
-                bool cand_fw = false, cand_rc = false;
-                for (int t = 0; t < M; ++t) {
-                    const uint32_t bt = bp[t * WAVE];
-                    const bool live_fw = open && t >= 1 && bt == a0;
-                    if (WAVE_ANY(live_fw))
-                        cand_fw |= tail_equals(bp, t, 1, M - t, 0u, stepbase, live_fw);
-                    const bool live_rc = open && t < M - 1 && (bt ^ 1u) == a0;
-                    if (WAVE_ANY(live_rc))
-                        cand_rc |= tail_equals(bp, t, -1, t + 1, 1u, stepbase, live_rc);
-                }
-                bad = open && !(cand_fw || cand_rc);
-                push_pairs(a, cand_fw, cand_rc, lane, (uint32_t)(tv.path0 + p), slot, M);
+        const uint32_t head = img[a.L.first_at() + (b0 >> 1)];
+        const uint32_t e = ((pass >> p) & 1u) ? head : ENT_NONE;
+        const lanemask found_m = subpath_search_long(bp, M, b0, e, img + a.L.next_at(),
+                                                     stepbase, a.L.nm, n);
+        const lanemask open_m = in_m & ~found_m;
+        lanemask bad_m = 0;
+        if (open_m != 0) {
+            const bool open = (open_m >> lane) & 1ull;
+            bool cand_fw = false, cand_rc = false;
+            for (int t = 0; t < M; ++t) {
+                const uint32_t bt = bp[t * WAVE];
+                const bool live_fw = open && t >= 1 && bt == a0;
+                if (WAVE_ANY(live_fw))
+                    cand_fw |= tail_equals(bp, t, 1, M - t, 0u, stepbase, live_fw);
+                const bool live_rc = open && t < M - 1 && (bt ^ 1u) == a0;
+                if (WAVE_ANY(live_rc))
+                    cand_rc |= tail_equals(bp, t, -1, t + 1, 1u, stepbase, live_rc);
             }
+            bad_m = open_m & ~WAVE_MASK(cand_fw || cand_rc);
+            push_pairs(a, cand_fw, cand_rc, lane, (uint32_t)(tv.path0 + p), slot, M);
         }
-        const uint32_t g = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(good));
-        const uint32_t d = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(bad));
-        if (lane == p) {
-            cnt_good += g;
-            cnt_bad += d;
-        }
+        wc.add(p, lane, found_m, bad_m);
     }
+    wc.item_done();
 }
 
-__global__ __launch_bounds__(SCAN_THREADS, 6) void k_scan(ScanArgs a)
+__global__ __launch_bounds__(SCAN_THREADS, 8) void k_scan(ScanArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     const int tid = threadIdx.x;
@@ -559,7 +594,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 6) void k_scan(ScanArgs a)
     }
     __syncthreads();
 
-    uint32_t cnt_good = 0, cnt_bad = 0;   // lane p: path0 + p
+    WaveCounts wc;                        // lane p: path0 + p
     const int item_begin = chunk * a.items_per_chunk;
     const int item_end = min(item_begin + a.items_per_chunk, a.items.n_items);
     for (int it = item_begin + wave; it < item_end; it += SCAN_WAVES) {
@@ -570,7 +605,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 6) void k_scan(ScanArgs a)
         switch (M) {
 #define GFAL_CASE(MM)                                                          \
     case MM:                                                                   \
-        scan_item<MM>(a, tv, bp, lane, slot, cnt_good, cnt_bad);               \
+        scan_item<MM>(a, tv, bp, lane, slot, wc);                              \
         break;
             GFAL_CASE(1) GFAL_CASE(2) GFAL_CASE(3) GFAL_CASE(4)
             GFAL_CASE(5) GFAL_CASE(6) GFAL_CASE(7) GFAL_CASE(8)
@@ -578,12 +613,14 @@ __global__ __launch_bounds__(SCAN_THREADS, 6) void k_scan(ScanArgs a)
             GFAL_CASE(13) GFAL_CASE(14) GFAL_CASE(15) GFAL_CASE(16)
 #undef GFAL_CASE
         default:
-            scan_item_long(a, tv, bp, M, lane, slot, cnt_good, cnt_bad);
+            scan_item_long(a, tv, bp, M, lane, slot, wc);
         }
     }
 
     // workgroup reduction through LDS (images are dead now), then one atomic
     // per counter per workgroup
+    wc.flush();
+    const uint32_t cnt_good = wc.good, cnt_bad = wc.bad;
     __syncthreads();
     uint32_t *red = reinterpret_cast<uint32_t *>(lds);
     if (tid < 2 * MAX_TILE) red[tid] = 0;
@@ -1349,11 +1386,11 @@ int gfal_scorer_score_device(gfal_scorer *s, const int32_t *d_path_off,
         d.wl_capacity = s->wl_capacity;
         d.row_scratch = s->d_rows;
         d.counts = d_counts;
-        hipLaunchKernelGGL((k_dp_regs<8, 0>), dim3(DP_BLOCKS), dim3(DP_THREADS), 0, st, d);
+        hipLaunchKernelGGL((k_dp_regs<8, 0>), dim3(DP_REG_BLOCKS), dim3(DP_THREADS), 0, st, d);
         if (s->max_aln_len > 8)
-            hipLaunchKernelGGL((k_dp_regs<16, 1>), dim3(DP_BLOCKS), dim3(DP_THREADS), 0, st, d);
+            hipLaunchKernelGGL((k_dp_regs<16, 1>), dim3(DP_REG_BLOCKS), dim3(DP_THREADS), 0, st, d);
         if (s->max_aln_len > 16)
-            hipLaunchKernelGGL((k_dp_regs<32, 2>), dim3(DP_BLOCKS), dim3(DP_THREADS), 0, st, d);
+            hipLaunchKernelGGL((k_dp_regs<32, 2>), dim3(DP_REG_BLOCKS), dim3(DP_THREADS), 0, st, d);
         if (s->max_aln_len > 32) {
             if (dp_rows_fit_lds(s->max_aln_len))
                 hipLaunchKernelGGL(k_dp_long<true>, dim3(DP_BLOCKS), dim3(DP_THREADS),
