@@ -54,6 +54,7 @@ constexpr uint32_t ENT_PRESENT = 0xFFFEu;  // node is on the path, but only as
                                            // steps that equal nothing
 constexpr uint32_t ENT_POS = 0x03FFu;      // position in the path (0..999)
 constexpr uint32_t ENT_NEG = 0x8000u;      // step there is '-'
+constexpr int NEXT_CAP = 1024;             // next[] is indexable by any ENT_POS value
 constexpr uint32_t STEP_NOMATCH = 0xFFFEu; // path step that equals nothing
 constexpr uint32_t STEP_INVALID = 0xFFFFu; // padding lane of an item
 constexpr int MAX_LOCAL_NODES = 32766;     // 2*V-1 must stay below STEP_NOMATCH
@@ -82,19 +83,23 @@ void set_err(const char *fmt, ...)
 
 // Geometry of one path image, in uint16 units.  Shared by host and device.
 //   first[v2]  node -> chain entry of its first occurrence on the path
-//   next[nm]   position -> chain entry of the node's next occurrence
+//   next[1024] position -> chain entry of the node's next occurrence; indexable
+//              by any 10-bit position, the tail beyond the path holds ENT_NONE
 //   step[nm]   the path's steps (local packed codes)
 //   rstep[nm]  the steps of the path's reverse complement
 //   len, pad
 struct ImageLayout {
     int v2;        // first-occurrence table entries (n_local rounded up to even)
-    int nm;        // capacity of the chain / step arrays (even, >= MAX_REG_M)
+    int nm;        // capacity of the step arrays (even, >= MAX_REG_M)
     int total;     // whole image, multiple of 8 (16 bytes)
     __host__ __device__ int first_at() const { return 0; }
     __host__ __device__ int next_at() const { return v2; }
-    __host__ __device__ int step_at() const { return v2 + nm; }
-    __host__ __device__ int rstep_at() const { return v2 + 2 * nm; }
-    __host__ __device__ int len_at() const { return v2 + 3 * nm; }
+    __host__ __device__ int step_at() const { return v2 + NEXT_CAP; }
+    __host__ __device__ int rstep_at() const { return v2 + NEXT_CAP + nm; }
+    __host__ __device__ int len_at() const { return v2 + NEXT_CAP + 2 * nm; }
+    // 16 entries of next[] that always hold ENT_NONE (0xFFFF): a window that
+    // equals no alignment steps, for lanes that have nothing to compare
+    __host__ __device__ int never_at() const { return v2 + NEXT_CAP - 16; }
 };
 
 ImageLayout make_layout(int n_local, int max_len)
@@ -102,7 +107,7 @@ ImageLayout make_layout(int n_local, int max_len)
     ImageLayout L;
     L.v2 = (n_local + 1) & ~1;
     L.nm = std::max((max_len + 1) & ~1, MAX_REG_M);
-    L.total = (L.v2 + 3 * L.nm + 2 + 7) & ~7;
+    L.total = (L.v2 + NEXT_CAP + 2 * L.nm + 2 + 7) & ~7;
     return L;
 }
 
@@ -341,72 +346,77 @@ struct WaveCounts {
 // Occurrence-chain search (DESIGN.md "k_scan"): is B a contiguous subpath of
 // the path, or of its reverse complement?  `e` = chain head for B[0]'s node
 // (ENT_NONE on lanes that take no part).  Both directions are forward scans:
-// the image holds the path's steps and, nm entries further, the steps of its
-// reverse complement.  Requires M <= n.  Branch-free body; the only branch is
-// the wave-level loop test.  Returns the lanes whose alignment was found.
+// the image holds the path's steps and, behind them, the steps of its reverse
+// complement.  Requires M <= n.  Branch-free body; the only branch is the
+// wave-level loop test.  Returns the lanes whose alignment was found.
+struct ChainView {
+    const uint16_t *next;     // next[NEXT_CAP]
+    const uint16_t *fwd;      // path steps
+    const uint16_t *rev;      // steps of the reverse complement
+    const uint16_t *never;    // 16 entries that equal no alignment step
+    int n;
+};
+
 template <int M>
 __device__ __forceinline__ lanemask subpath_search(const uint32_t (&b)[M], uint32_t e,
-                                                   const uint16_t *next,
-                                                   const uint16_t *stepbase, int nm, int n)
+                                                   const ChainView &cv)
 {
-    lanemask found = 0;
-    const uint32_t o0 = b[0] & 1u;
-    const uint32_t last_start = (uint32_t)(n - M);
-    const uint32_t n1 = (uint32_t)(n - 1);
-    const uint32_t next_cap = (uint32_t)(nm - 1);
+#if defined(GFAL_ABLATE) && GFAL_ABLATE == 1
+    return WAVE_MASK(e < ENT_PRESENT);
+#endif
+    bool found = false;
+    const uint32_t o0 = (b[0] & 1u) << 15;
+    const uint32_t last_start = (uint32_t)(cv.n - M);
+    const uint32_t n1 = (uint32_t)(cv.n - 1);
     while (true) {
         const uint32_t pos = e & ENT_POS;
-        // dir 0: the path step at pos equals b0 -> B may start there.
-        // dir 1: it is b0's complement -> B may start at n-1-pos of rc(path).
-        const uint32_t dir = (e >> 15) ^ o0;
-        const uint32_t start = dir ? n1 - pos : pos;
+        // same orientation as b0: B may start at pos of the path; opposite:
+        // B may start at n-1-pos of its reverse complement
+        const bool rc = (e & ENT_NEG) != o0;
+        const uint32_t start = rc ? n1 - pos : pos;
         // terminal entries decode to pos 1023/1022: start > n - M either way
         const bool fits = start <= last_start;
-        const uint32_t at = fits ? dir * (uint32_t)nm + start : 0u;   // else stepbase[0..M)
-        const uint16_t *w = stepbase + at;
-        const uint32_t nx = next[min(pos, next_cap)];
+        const uint16_t *w = (rc ? cv.rev : cv.fwd) + start;
+        w = fits ? w : cv.never;
+        const uint32_t nx = cv.next[pos];
         bool ok = fits;
 #pragma unroll
         for (int t = 1; t < M; ++t) ok &= (uint32_t)w[t] == b[t];
-        found |= WAVE_MASK(ok);
-        const bool more = e < ENT_PRESENT && !ok;
-        e = more ? nx : ENT_NONE;
+        found |= ok;
+        e = ok ? ENT_NONE : nx;     // next[1022..1023] hold ENT_NONE
         if (!WAVE_ANY(e < ENT_PRESENT)) break;
     }
-    return found;
+    return WAVE_MASK(found);
 }
 
 __device__ __forceinline__ lanemask subpath_search_long(const uint16_t *__restrict__ bp,
                                                         int M, uint32_t b0, uint32_t e,
-                                                        const uint16_t *next,
-                                                        const uint16_t *stepbase, int nm,
-                                                        int n)
+                                                        const ChainView &cv)
 {
-    lanemask found = 0;
-    const uint32_t o0 = b0 & 1u;
-    const uint32_t last_start = (uint32_t)(n - M);
-    const uint32_t n1 = (uint32_t)(n - 1);
-    const uint32_t next_cap = (uint32_t)(nm - 1);
+    bool found = false;
+    const uint32_t o0 = (b0 & 1u) << 15;
+    const uint32_t last_start = (uint32_t)(cv.n - M);
+    const uint32_t n1 = (uint32_t)(cv.n - 1);
     while (true) {
         const uint32_t pos = e & ENT_POS;
-        const uint32_t dir = (e >> 15) ^ o0;
-        const uint32_t start = dir ? n1 - pos : pos;
+        const bool rc = (e & ENT_NEG) != o0;
+        const uint32_t start = rc ? n1 - pos : pos;
         const bool fits = start <= last_start;
-        const uint32_t at = fits ? dir * (uint32_t)nm + start : 0u;
-        const uint16_t *w = stepbase + at;
-        const uint32_t nx = next[min(pos, next_cap)];
+        const uint16_t *w = (rc ? cv.rev : cv.fwd) + start;
+        const uint32_t nx = cv.next[pos];
         bool ok = fits;
-        // wave-uniform trip count; a lane that does not fit compares against
-        // stepbase[0] throughout (in range) and stays false
+        // wave-uniform trip count; a lane that does not fit re-reads one
+        // never-matching entry and stays false
         const int lim = WAVE_ANY(fits) ? M : 1;
-        for (int t = 1; t < lim; ++t)
-            ok &= (uint32_t)w[fits ? t : 0] == (uint32_t)bp[t * WAVE];
-        found |= WAVE_MASK(ok);
-        const bool more = e < ENT_PRESENT && !ok;
-        e = more ? nx : ENT_NONE;
+        for (int t = 1; t < lim; ++t) {
+            const uint16_t *q = fits ? w + t : cv.never;
+            ok &= (uint32_t)*q == (uint32_t)bp[t * WAVE];
+        }
+        found |= ok;
+        e = ok ? ENT_NONE : nx;
         if (!WAVE_ANY(e < ENT_PRESENT)) break;
     }
-    return found;
+    return WAVE_MASK(found);
 }
 
 // One item against the tile: M is the template constant and b[] holds the
@@ -435,20 +445,32 @@ __device__ __forceinline__ void scan_item(const ScanArgs &a, const TileView &tv,
     // positions of the path's first step inside B, refreshed when a0 changes
     uint32_t cached_a0 = 0xFFFFFFFFu, a0_fw = 0, a0_rc = 0;
 
+    lanemask a0_any = 0;    // lanes with a0_fw | a0_rc != 0
+
     for (int p = 0; p < tv.tile_paths; ++p) {
-        const lanemask in_m = WAVE_MASK(((pass >> p) & 1u) != 0u);
+        const bool in = ((pass >> p) & 1u) != 0u;
+        const lanemask in_m = WAVE_MASK(in);
         if (in_m == 0) continue;
         const int n = __builtin_amdgcn_readlane(tv.hdr_n, p);
         if (M > n) {                      // src/alignments.cpp:500 row-0 bound:
-            wc.add(p, lane, in_m, 0);           // longer than the path -> good
+            wc.add(p, lane, in_m, 0);     // longer than the path -> good
             continue;
         }
         const uint16_t *img = tv.lds + p * a.L.total;
         const uint16_t *stepbase = img + a.L.step_at();
+        ChainView cv;
+        cv.next = img + a.L.next_at();
+        cv.fwd = stepbase;
+        cv.rev = img + a.L.rstep_at();
+        cv.never = img + a.L.never_at();
+        cv.n = n;
+#if defined(GFAL_ABLATE) && GFAL_ABLATE == 2
+        wc.add(p, lane, in_m, 0);
+        continue;
+#endif
         const uint32_t head = img[a.L.first_at() + node0];
-        const uint32_t e = ((pass >> p) & 1u) ? head : ENT_NONE;
-        const lanemask found_m =
-            subpath_search<M>(b, e, img + a.L.next_at(), stepbase, a.L.nm, n);
+        const uint32_t e = in ? head : ENT_NONE;
+        const lanemask found_m = subpath_search<M>(b, e, cv);
         const lanemask open_m = in_m & ~found_m;
         lanemask bad_m = 0;
         if (open_m != 0) {
@@ -465,8 +487,9 @@ __device__ __forceinline__ void scan_item(const ScanArgs &a, const TileView &tv,
 #pragma unroll
                 for (int t = 0; t < M - 1; ++t)
                     a0_rc |= ((b[t] ^ 1u) == a0) ? (1u << t) : 0u;
+                a0_any = WAVE_MASK((a0_fw | a0_rc) != 0u);
             }
-            const lanemask maybe_m = open_m & WAVE_MASK((a0_fw | a0_rc) != 0u);
+            const lanemask maybe_m = open_m & a0_any;
             lanemask cand_m = 0;
             if (maybe_m != 0) {
                 const bool open = (open_m >> lane) & 1ull;
@@ -519,10 +542,15 @@ __device__ __forceinline__ void scan_item_long(const ScanArgs &a, const TileView
         const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)tv.hdr_a0, p);
         const uint16_t *img = tv.lds + p * a.L.total;
         const uint16_t *stepbase = img + a.L.step_at();
+        ChainView cv;
+        cv.next = img + a.L.next_at();
+        cv.fwd = stepbase;
+        cv.rev = img + a.L.rstep_at();
+        cv.never = img + a.L.never_at();
+        cv.n = n;
         const uint32_t head = img[a.L.first_at() + (b0 >> 1)];
         const uint32_t e = ((pass >> p) & 1u) ? head : ENT_NONE;
-        const lanemask found_m = subpath_search_long(bp, M, b0, e, img + a.L.next_at(),
-                                                     stepbase, a.L.nm, n);
+        const lanemask found_m = subpath_search_long(bp, M, b0, e, cv);
         const lanemask open_m = in_m & ~found_m;
         lanemask bad_m = 0;
         if (open_m != 0) {
