@@ -82,11 +82,20 @@ def main():
                      "(one rank per GPU)" % args.gpus)
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no CPU fallback on the product path)")
+    # Rehearsal on a one-GPU box (GFALIGN_BENCH_REHEARSAL=1): every rank uses
+    # cuda:0 and the counters are all-reduced over gloo through the host.  The
+    # driver's multi-GPU runs never set it: one rank per GPU, RCCL over xGMI.
+    rehearsal = os.environ.get("GFALIGN_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     t = synth.make(args.workload)
     t.name = args.workload
@@ -104,7 +113,12 @@ def main():
     def step():
         sc.score_device(d_off.data_ptr(), d_steps.data_ptr(), P, total_steps, max_len,
                         True, d_counts.data_ptr(), stream.cuda_stream)
-        shard.all_reduce_counts(d_counts)
+        if rehearsal and world > 1:
+            host = d_counts.cpu()
+            shard.all_reduce_counts(host)
+            d_counts.copy_(host)
+        else:
+            shard.all_reduce_counts(d_counts)
 
     for _ in range(args.warmup):
         step()
@@ -127,7 +141,7 @@ def main():
     info = sc.info()
     sc.set_profiling(False)
 
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    el = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
@@ -188,6 +202,9 @@ def main():
                         "LDS, so achieved may exceed the HBM peak (DESIGN.md)",
             },
         }
+        out["config"]["counter_checksum"] = int(bad.astype(np.uint64).sum() * 3 +
+                                                 good.astype(np.uint64).sum() * 5 +
+                                                 una.astype(np.uint64).sum() * 7)
         if world == 1 and not args.no_cpu_baseline:
             base, (pick, n_aln, ebad, egood, euna) = cpu_baseline(t)
             out["cpu_baseline"] = base

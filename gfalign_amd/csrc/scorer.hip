@@ -38,7 +38,7 @@
 namespace {
 
 constexpr int WAVE = 64;
-constexpr int SCAN_THREADS = 1024;
+constexpr int SCAN_THREADS = 768;
 constexpr int SCAN_WAVES = SCAN_THREADS / WAVE;
 constexpr int MAX_REG_M = 16;          // alignments up to this length live in VGPRs
 constexpr int MAX_TILE = 32;           // one bit per tile path in the node masks
@@ -55,6 +55,7 @@ constexpr uint32_t ENT_PRESENT = 0xFFFEu;  // node is on the path, but only as
 constexpr uint32_t ENT_POS = 0x03FFu;      // position in the path (0..999)
 constexpr uint32_t ENT_NEG = 0x8000u;      // step there is '-'
 constexpr int NEXT_CAP = 1024;             // next[] is indexable by any ENT_POS value
+constexpr int NEVER_LEN = 32;              // uint16 entries of the never-matching window
 constexpr uint32_t STEP_NOMATCH = 0xFFFEu; // path step that equals nothing
 constexpr uint32_t STEP_INVALID = 0xFFFFu; // padding lane of an item
 constexpr int MAX_LOCAL_NODES = 32766;     // 2*V-1 must stay below STEP_NOMATCH
@@ -82,32 +83,35 @@ void set_err(const char *fmt, ...)
     } while (0)
 
 // Geometry of one path image, in uint16 units.  Shared by host and device.
-//   first[v2]  node -> chain entry of its first occurrence on the path
-//   next[1024] position -> chain entry of the node's next occurrence; indexable
-//              by any 10-bit position, the tail beyond the path holds ENT_NONE
-//   step[nm]   the path's steps (local packed codes)
-//   rstep[nm]  the steps of the path's reverse complement
+// Every section starts on a 4-byte boundary: the scan kernel reads the image
+// with 32-bit LDS loads only (a ds_read_u16 costs 12-16 LDS cycles per
+// wave-instruction on gfx950, a ds_read_b32 2.4; tools/lds_rate.hip).
+//   first[v2]    node -> chain entry of its first occurrence on the path
+//   next[1024]   uint32 per position: chain entry of the node's next
+//                occurrence; indexable by any 10-bit position, the tail beyond
+//                the path holds ENT_NONE
+//   step[nm]     the path's steps (local packed codes), 0xFFFF beyond n
+//   rstep[nm]    the steps of the path's reverse complement
+//   never[32]    0xFFFF: a window that equals no alignment steps
 //   len, pad
 struct ImageLayout {
     int v2;        // first-occurrence table entries (n_local rounded up to even)
-    int nm;        // capacity of the step arrays (even, >= MAX_REG_M)
+    int nm;        // capacity of the step arrays (even, >= n + 2, >= 2 * MAX_REG_M)
     int total;     // whole image, multiple of 8 (16 bytes)
     __host__ __device__ int first_at() const { return 0; }
     __host__ __device__ int next_at() const { return v2; }
-    __host__ __device__ int step_at() const { return v2 + NEXT_CAP; }
-    __host__ __device__ int rstep_at() const { return v2 + NEXT_CAP + nm; }
-    __host__ __device__ int len_at() const { return v2 + NEXT_CAP + 2 * nm; }
-    // 16 entries of next[] that always hold ENT_NONE (0xFFFF): a window that
-    // equals no alignment steps, for lanes that have nothing to compare
-    __host__ __device__ int never_at() const { return v2 + NEXT_CAP - 16; }
+    __host__ __device__ int step_at() const { return v2 + 2 * NEXT_CAP; }
+    __host__ __device__ int rstep_at() const { return v2 + 2 * NEXT_CAP + nm; }
+    __host__ __device__ int never_at() const { return v2 + 2 * NEXT_CAP + 2 * nm; }
+    __host__ __device__ int len_at() const { return v2 + 2 * NEXT_CAP + 2 * nm + NEVER_LEN; }
 };
 
 ImageLayout make_layout(int n_local, int max_len)
 {
     ImageLayout L;
     L.v2 = (n_local + 1) & ~1;
-    L.nm = std::max((max_len + 1) & ~1, MAX_REG_M);
-    L.total = (L.v2 + NEXT_CAP + 2 * L.nm + 2 + 7) & ~7;
+    L.nm = std::max((max_len + 3) & ~1, 2 * MAX_REG_M);
+    L.total = (L.len_at() + 2 + 7) & ~7;
     return L;
 }
 
@@ -150,10 +154,12 @@ __global__ __launch_bounds__(WAVE) void k_prep(
     }
 
     uint16_t *first = img + L.first_at();
-    uint16_t *next = img + L.next_at();
+    uint32_t *next = reinterpret_cast<uint32_t *>(img + L.next_at());
     uint16_t *step = img + L.step_at();
     uint16_t *rstep = img + L.rstep_at();
     for (int i = lane; i < L.total; i += WAVE) img[i] = (uint16_t)ENT_NONE;
+    __syncthreads();
+    for (int i = lane; i < NEXT_CAP; i += WAVE) next[i] = ENT_NONE;
     __syncthreads();
 
     bool id_ok = true;
@@ -193,7 +199,7 @@ __global__ __launch_bounds__(WAVE) void k_prep(
                 if (head == ENT_NONE) first[lid] = (uint16_t)ENT_PRESENT;
                 continue;
             }
-            next[i] = (uint16_t)(head == ENT_PRESENT ? ENT_NONE : head);
+            next[i] = head == ENT_PRESENT ? ENT_NONE : head;
             first[lid] = (uint16_t)((uint32_t)i | ((code & 1u) ? ENT_NEG : 0u));
         }
         img[L.len_at()] = (uint16_t)n;
@@ -301,16 +307,23 @@ __device__ __forceinline__ void push_pairs(const ScanArgs &a, bool fw, bool rc, 
     }
 }
 
+// uint16 entry i of a 4-byte aligned LDS array, fetched with a 32-bit load.
+__device__ __forceinline__ uint32_t lds_u16(const uint32_t *base32, uint32_t i)
+{
+    return (base32[i >> 1] >> ((i & 1u) << 4)) & 0xFFFFu;
+}
+
 // live lanes: does B[start + dirn*k] ^ flipbit equal path step k for k in
 // [1, len)?  (k = 0 was checked by the caller.)  len, start, dirn are
 // wave-uniform; B is re-read from the item (coalesced, cache-hot).
 __device__ __forceinline__ bool tail_equals(const uint16_t *__restrict__ bp, int start,
                                             int dirn, int len, uint32_t flipbit,
-                                            const uint16_t *step, bool live)
+                                            const uint32_t *step32, bool live)
 {
     bool eq = live;
     for (int k = 1; k < len; ++k)
-        eq &= ((uint32_t)bp[(start + dirn * k) * WAVE] ^ flipbit) == (uint32_t)step[k];
+        eq &= ((uint32_t)bp[(start + dirn * k) * WAVE] ^ flipbit) ==
+              lds_u16(step32, (uint32_t)k);
     return eq;
 }
 
@@ -346,26 +359,26 @@ struct WaveCounts {
 // Occurrence-chain search (DESIGN.md "k_scan"): is B a contiguous subpath of
 // the path, or of its reverse complement?  `e` = chain head for B[0]'s node
 // (ENT_NONE on lanes that take no part).  Both directions are forward scans:
-// the image holds the path's steps and, behind them, the steps of its reverse
-// complement.  Requires M <= n.  Branch-free body; the only branch is the
-// wave-level loop test.  Returns the lanes whose alignment was found.
+// step32 views, as dwords, the path's steps, then (nm entries further) the
+// steps of its reverse complement, then the never-matching window.  Requires
+// M <= n.  Branch-free body; the only branch is the wave-level loop test.
+// Returns the lanes whose alignment was found.
 struct ChainView {
-    const uint16_t *next;     // next[NEXT_CAP]
-    const uint16_t *fwd;      // path steps
-    const uint16_t *rev;      // steps of the reverse complement
-    const uint16_t *never;    // 16 entries that equal no alignment step
+    const uint32_t *next;     // next[NEXT_CAP]
+    const uint32_t *step32;   // step[nm] | rstep[nm] | never[NEVER_LEN]
+    uint32_t nm;
     int n;
 };
 
+// pairs[k] = b[1 + 2k] | b[2 + 2k] << 16: steps 1..M-1 two to a dword.
 template <int M>
-__device__ __forceinline__ lanemask subpath_search(const uint32_t (&b)[M], uint32_t e,
+__device__ __forceinline__ lanemask subpath_search(const uint32_t (&pairs)[(M / 2) ? (M / 2) : 1],
+                                                   uint32_t o0, uint32_t e,
                                                    const ChainView &cv)
 {
-#if defined(GFAL_ABLATE) && GFAL_ABLATE == 1
-    return WAVE_MASK(e < ENT_PRESENT);
-#endif
+    constexpr int K = M / 2;          // dwords of alignment steps to compare
+    constexpr int KD = (M + 1) / 2;   // dwords of path steps that cover them
     bool found = false;
-    const uint32_t o0 = (b[0] & 1u) << 15;
     const uint32_t last_start = (uint32_t)(cv.n - M);
     const uint32_t n1 = (uint32_t)(cv.n - 1);
     while (true) {
@@ -376,12 +389,27 @@ __device__ __forceinline__ lanemask subpath_search(const uint32_t (&b)[M], uint3
         const uint32_t start = rc ? n1 - pos : pos;
         // terminal entries decode to pos 1023/1022: start > n - M either way
         const bool fits = start <= last_start;
-        const uint16_t *w = (rc ? cv.rev : cv.fwd) + start;
-        w = fits ? w : cv.never;
+        // uint16 index of the first step to compare (step 1 of the window)
+        uint32_t idx = start + (rc ? cv.nm + 1u : 1u);
+        idx = fits ? idx : 2u * cv.nm;
         const uint32_t nx = cv.next[pos];
         bool ok = fits;
+        if (M > 1) {
+            const uint32_t *wd = cv.step32 + (idx >> 1);
+            const uint32_t sh = idx << 4;          // alignbit uses bits 4:0: 0 or 16
+            uint32_t d[KD];
 #pragma unroll
-        for (int t = 1; t < M; ++t) ok &= (uint32_t)w[t] == b[t];
+            for (int k = 0; k < KD; ++k) d[k] = wd[k];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const uint32_t hi = d[(k + 1 < KD) ? k + 1 : k];
+                const uint32_t got = __builtin_amdgcn_alignbit(hi, d[k], sh);
+                if (2 * k + 2 < M)
+                    ok &= got == pairs[k];
+                else        // last pair holds one step only
+                    ok &= (uint16_t)got == (uint16_t)pairs[k];
+            }
+        }
         found |= ok;
         e = ok ? ENT_NONE : nx;     // next[1022..1023] hold ENT_NONE
         if (!WAVE_ANY(e < ENT_PRESENT)) break;
@@ -402,15 +430,15 @@ __device__ __forceinline__ lanemask subpath_search_long(const uint16_t *__restri
         const bool rc = (e & ENT_NEG) != o0;
         const uint32_t start = rc ? n1 - pos : pos;
         const bool fits = start <= last_start;
-        const uint16_t *w = (rc ? cv.rev : cv.fwd) + start;
+        const uint32_t idx = fits ? start + (rc ? cv.nm : 0u) : 2u * cv.nm;
         const uint32_t nx = cv.next[pos];
         bool ok = fits;
-        // wave-uniform trip count; a lane that does not fit re-reads one
-        // never-matching entry and stays false
+        // wave-uniform trip count; a lane that does not fit re-reads the
+        // never-matching window and stays false
         const int lim = WAVE_ANY(fits) ? M : 1;
         for (int t = 1; t < lim; ++t) {
-            const uint16_t *q = fits ? w + t : cv.never;
-            ok &= (uint32_t)*q == (uint32_t)bp[t * WAVE];
+            const uint32_t at = fits ? idx + (uint32_t)t : idx;
+            ok &= lds_u16(cv.step32, at) == (uint32_t)bp[t * WAVE];
         }
         found |= ok;
         e = ok ? ENT_NONE : nx;
@@ -441,10 +469,16 @@ __device__ __forceinline__ void scan_item(const ScanArgs &a, const TileView &tv,
 #pragma unroll
         for (int t = 0; t < M; ++t) pass &= tv.nodemask[b[t] >> 1];
     }
-    const uint32_t node0 = b[0] >> 1;
+    // the head lookup reads first[] (uint16 entries) through a dword
+    const uint32_t node0_word = b[0] >> 2, node0_shift = (b[0] & 2u) << 3;
+    const uint32_t o0 = (b[0] & 1u) << 15;
+    uint32_t pairs[(M / 2) ? (M / 2) : 1];
+    pairs[0] = 0;
+#pragma unroll
+    for (int k = 0; k < M / 2; ++k)
+        pairs[k] = b[1 + 2 * k] | ((2 * k + 2 < M) ? (b[2 + 2 * k] << 16) : 0u);
     // positions of the path's first step inside B, refreshed when a0 changes
     uint32_t cached_a0 = 0xFFFFFFFFu, a0_fw = 0, a0_rc = 0;
-
     lanemask a0_any = 0;    // lanes with a0_fw | a0_rc != 0
 
     for (int p = 0; p < tv.tile_paths; ++p) {
@@ -457,20 +491,20 @@ __device__ __forceinline__ void scan_item(const ScanArgs &a, const TileView &tv,
             continue;
         }
         const uint16_t *img = tv.lds + p * a.L.total;
-        const uint16_t *stepbase = img + a.L.step_at();
+        const uint32_t *img32 = reinterpret_cast<const uint32_t *>(img);
+        const uint32_t *step32 = img32 + a.L.step_at() / 2;
         ChainView cv;
-        cv.next = img + a.L.next_at();
-        cv.fwd = stepbase;
-        cv.rev = img + a.L.rstep_at();
-        cv.never = img + a.L.never_at();
+        cv.next = img32 + a.L.next_at() / 2;
+        cv.step32 = step32;
+        cv.nm = (uint32_t)a.L.nm;
         cv.n = n;
 #if defined(GFAL_ABLATE) && GFAL_ABLATE == 2
         wc.add(p, lane, in_m, 0);
         continue;
 #endif
-        const uint32_t head = img[a.L.first_at() + node0];
+        const uint32_t head = (img32[node0_word] >> node0_shift) & 0xFFFFu;
         const uint32_t e = in ? head : ENT_NONE;
-        const lanemask found_m = subpath_search<M>(b, e, cv);
+        const lanemask found_m = subpath_search<M>(pairs, o0, e, cv);
         const lanemask open_m = in_m & ~found_m;
         lanemask bad_m = 0;
         if (open_m != 0) {
@@ -498,13 +532,13 @@ __device__ __forceinline__ void scan_item(const ScanArgs &a, const TileView &tv,
                 for (int t = 1; t < M; ++t) {      // B[t..M) == path[0..M-t) ?
                     const bool live = open && ((a0_fw >> t) & 1u);
                     if (WAVE_ANY(live))
-                        cand_fw |= tail_equals(bp, t, 1, M - t, 0u, stepbase, live);
+                        cand_fw |= tail_equals(bp, t, 1, M - t, 0u, step32, live);
                 }
 #pragma unroll
                 for (int t = 0; t < M - 1; ++t) {  // rc(B)[M-1-t..M) == path[0..t+1) ?
                     const bool live = open && ((a0_rc >> t) & 1u);
                     if (WAVE_ANY(live))
-                        cand_rc |= tail_equals(bp, t, -1, t + 1, 1u, stepbase, live);
+                        cand_rc |= tail_equals(bp, t, -1, t + 1, 1u, step32, live);
                 }
                 cand_m = WAVE_MASK(cand_fw || cand_rc);
                 push_pairs(a, cand_fw, cand_rc, lane, (uint32_t)(tv.path0 + p), slot, M);
@@ -541,14 +575,14 @@ __device__ __forceinline__ void scan_item_long(const ScanArgs &a, const TileView
         }
         const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)tv.hdr_a0, p);
         const uint16_t *img = tv.lds + p * a.L.total;
-        const uint16_t *stepbase = img + a.L.step_at();
+        const uint32_t *img32 = reinterpret_cast<const uint32_t *>(img);
+        const uint32_t *step32 = img32 + a.L.step_at() / 2;
         ChainView cv;
-        cv.next = img + a.L.next_at();
-        cv.fwd = stepbase;
-        cv.rev = img + a.L.rstep_at();
-        cv.never = img + a.L.never_at();
+        cv.next = img32 + a.L.next_at() / 2;
+        cv.step32 = step32;
+        cv.nm = (uint32_t)a.L.nm;
         cv.n = n;
-        const uint32_t head = img[a.L.first_at() + (b0 >> 1)];
+        const uint32_t head = lds_u16(img32, b0 >> 1);
         const uint32_t e = ((pass >> p) & 1u) ? head : ENT_NONE;
         const lanemask found_m = subpath_search_long(bp, M, b0, e, cv);
         const lanemask open_m = in_m & ~found_m;
@@ -560,10 +594,10 @@ __device__ __forceinline__ void scan_item_long(const ScanArgs &a, const TileView
                 const uint32_t bt = bp[t * WAVE];
                 const bool live_fw = open && t >= 1 && bt == a0;
                 if (WAVE_ANY(live_fw))
-                    cand_fw |= tail_equals(bp, t, 1, M - t, 0u, stepbase, live_fw);
+                    cand_fw |= tail_equals(bp, t, 1, M - t, 0u, step32, live_fw);
                 const bool live_rc = open && t < M - 1 && (bt ^ 1u) == a0;
                 if (WAVE_ANY(live_rc))
-                    cand_rc |= tail_equals(bp, t, -1, t + 1, 1u, stepbase, live_rc);
+                    cand_rc |= tail_equals(bp, t, -1, t + 1, 1u, step32, live_rc);
             }
             bad_m = open_m & ~WAVE_MASK(cand_fw || cand_rc);
             push_pairs(a, cand_fw, cand_rc, lane, (uint32_t)(tv.path0 + p), slot, M);
@@ -573,7 +607,7 @@ __device__ __forceinline__ void scan_item_long(const ScanArgs &a, const TileView
     wc.item_done();
 }
 
-__global__ __launch_bounds__(SCAN_THREADS, 8) void k_scan(ScanArgs a)
+__global__ __launch_bounds__(SCAN_THREADS, 6) void k_scan(ScanArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     const int tid = threadIdx.x;
@@ -608,11 +642,16 @@ __global__ __launch_bounds__(SCAN_THREADS, 8) void k_scan(ScanArgs a)
     __syncthreads();
     // which tile paths carry each node (the filter of src/eval.cpp:81-91 as a
     // bit test): read off the first-occurrence tables just staged
-    for (int v = tid; v < a.L.v2; v += SCAN_THREADS) {
-        uint32_t m = 0;
-        for (int p = 0; p < tv.tile_paths; ++p)
-            m |= (lds[p * a.L.total + a.L.first_at() + v] != ENT_NONE) ? (1u << p) : 0u;
-        nodemask[v] = m;
+    for (int v2 = tid; v2 < a.L.v2 / 2; v2 += SCAN_THREADS) {    // two nodes per dword
+        uint32_t m_lo = 0, m_hi = 0;
+        for (int p = 0; p < tv.tile_paths; ++p) {
+            const uint32_t w = reinterpret_cast<const uint32_t *>(
+                lds + (size_t)p * a.L.total + a.L.first_at())[v2];
+            m_lo |= ((w & 0xFFFFu) != ENT_NONE) ? (1u << p) : 0u;
+            m_hi |= ((w >> 16) != ENT_NONE) ? (1u << p) : 0u;
+        }
+        nodemask[2 * v2] = m_lo;
+        nodemask[2 * v2 + 1] = m_hi;
     }
     tv.hdr_n = 0;
     tv.hdr_a0 = STEP_NOMATCH;
