@@ -188,20 +188,23 @@ __global__ __launch_bounds__(WAVE) void k_prep(
     // Steps that equal nothing (STEP_NOMATCH) are left out of the chains; a
     // node that only has such steps gets ENT_PRESENT (it still passes the
     // filter).  Bit 15 of lids[] marks the last occurrence of each node.
-    if (lane == 0) {
-        for (int i = n - 1; i >= 0; --i) {
-            const uint32_t lid = lids[i];
-            if (lid == ENT_NONE) continue;
-            const uint32_t head = first[lid];
-            if (head == ENT_NONE) lids[i] = (uint16_t)(lid | 0x8000u);
-            const uint32_t code = step[i];
-            if (code == STEP_NOMATCH) {
-                if (head == ENT_NONE) first[lid] = (uint16_t)ENT_PRESENT;
-                continue;
-            }
-            next[i] = head == ENT_PRESENT ? ENT_NONE : head;
-            first[lid] = (uint16_t)((uint32_t)i | ((code & 1u) ? ENT_NEG : 0u));
+    // Lane l owns the nodes with lid % 64 == l: every lane walks the whole
+    // path (uniform LDS reads) and updates only its own chains, so the 64
+    // lanes build disjoint chains concurrently.
+    for (int i = n - 1; i >= 0; --i) {
+        const uint32_t lid = lids[i];
+        if (lid == ENT_NONE || (int)(lid & 63u) != lane) continue;
+        const uint32_t head = first[lid];
+        if (head == ENT_NONE) lids[i] = (uint16_t)(lid | 0x8000u);
+        const uint32_t code = step[i];
+        if (code == STEP_NOMATCH) {
+            if (head == ENT_NONE) first[lid] = (uint16_t)ENT_PRESENT;
+            continue;
         }
+        next[i] = head == ENT_PRESENT ? ENT_NONE : head;
+        first[lid] = (uint16_t)((uint32_t)i | ((code & 1u) ? ENT_NEG : 0u));
+    }
+    if (lane == 0) {
         img[L.len_at()] = (uint16_t)n;
         img[L.len_at() + 1] = 0;
     }

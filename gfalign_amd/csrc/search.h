@@ -3,9 +3,9 @@
 // The best-first expansion of reference src/eval.cpp:110-193 stays on the
 // host; every call of evaluatePath (src/eval.cpp:162) goes through the C ABI
 // of include/gfalign_scorer.h.  Scores are pure functions of the candidate
-// path, so the children of the K best queue entries are scored in one batch
-// ahead of time; entries are still popped, extended, enqueued and printed in
-// exactly the reference's order.
+// path, so whole subtrees under the best queue entries are scored in one batch
+// ahead of time (see class Search); entries are still popped, extended,
+// enqueued and printed in exactly the reference's order.
 #ifndef GFALIGN_SEARCH_H
 #define GFALIGN_SEARCH_H
 
@@ -179,10 +179,19 @@ struct SearchOptions {
     uint32_t max_steps = 100000;   // include/input-gfalign.h:12
     uint32_t min_nodes = 0;
     bool return_all_paths = false;
-    size_t speculate = 512;        // queue entries whose children are scored per batch
+    size_t speculate = 128;        // candidate paths scored per GPU batch (target)
 };
 
 // reference src/eval.cpp:110-193
+//
+// Batching.  The reference scores the extensions of one queue entry per step
+// (src/eval.cpp:162), a handful of paths.  Scores are pure functions of the
+// path, and so are the extensions themselves (orientation gate, budgets), so
+// whenever the front entry has no scored extensions yet, its whole subtree is
+// generated breadth-first -- and that of the next best queue entries -- until
+// about `speculate` candidate paths are collected; they are scored in ONE call.
+// Entries are still popped, extended, enqueued and printed in exactly the
+// reference's order; speculation that is never popped is only wasted work.
 class Search {
 public:
     Search(const Graph &g, PathScorer &scorer, const SearchOptions &opt, std::ostream &out)
@@ -194,8 +203,7 @@ public:
         if (!table.load(opt_.node_file, g_)) return EXIT_FAILURE;           // :126
         table.add(opt_.source, g_.id_or_zero(opt_.source), 1);             // :127
         table.add(opt_.destination, g_.id_or_zero(opt_.destination), 1);   // :128
-        table_ = &table;
-        const uint32_t dest_uid = table.records[table.index.at(opt_.destination)].uid;
+        dest_uid_ = table.records[table.index.at(opt_.destination)].uid;
         const uint32_t src_uid = table.records[table.index.at(opt_.source)].uid;
 
         // per-uid record index for the budget gate (:142-143); -1 = not listed
@@ -208,7 +216,7 @@ public:
                 record_of_[table.records[r].uid] = (int)r;
         }
 
-        auto first = std::make_unique<Entry>();
+        auto first = std::make_unique<Node>();
         first->path.push_back({(int32_t)src_uid, '0'});                     // :130
         first->budget.resize(table.records.size());
         for (size_t r = 0; r < table.records.size(); ++r) first->budget[r] = table.records[r].count;
@@ -218,33 +226,29 @@ public:
         uint32_t steps = 0, best_uniques = 0;
         int32_t best_alt = INT32_MAX;
         while (!queue_.empty() && steps < opt_.max_steps) {                 // :134
-            if (!queue_.begin()->second->expanded && !expand_front()) return EXIT_FAILURE;
-            std::unique_ptr<Entry> u = std::move(queue_.begin()->second);   // :135
+            if (!queue_.begin()->second->kids_scored && !expand_front()) return EXIT_FAILURE;
+            std::unique_ptr<Node> u = std::move(queue_.begin()->second);    // :135
             queue_.erase(queue_.begin());
-            for (Child &c : u->children) {                                  // :136-185
+            for (std::unique_ptr<Node> &c : u->kids) {                      // :136-185
                 const int32_t alt =
-                    (int32_t)c.bad - (int32_t)c.good - (int32_t)c.uniques;  // :163
-                if ((uint32_t)c.path.back().id != dest_uid) {               // :165-169
-                    auto e = std::make_unique<Entry>();
-                    e->budget = u->budget;
-                    --e->budget[(size_t)c.record];
-                    e->path = std::move(c.path);
-                    queue_.emplace(Key{alt, seq_++}, std::move(e));
+                    (int32_t)c->bad - (int32_t)c->good - (int32_t)c->uniques;   // :163
+                if (!c->at_destination) {                                   // :165-169
+                    queue_.emplace(Key{alt, seq_++}, std::move(c));
                 } else {                                                    // :170-184
                     ++path_counter;
-                    const bool ham = table.hamiltonian(c.path);
+                    const bool ham = table.hamiltonian(c->path);
                     bool print = false;
-                    if (c.uniques >= opt_.min_nodes &&
-                        (best_uniques < c.uniques ||
-                         (best_uniques == c.uniques && best_alt > alt))) {
+                    if (c->uniques >= opt_.min_nodes &&
+                        (best_uniques < c->uniques ||
+                         (best_uniques == c->uniques && best_alt > alt))) {
                         best_alt = alt;
-                        best_uniques = c.uniques;
+                        best_uniques = c->uniques;
                         print = true;
                     }
                     if (opt_.return_all_paths || print)
-                        out_ << path_counter << '\t' << c.bad << '\t' << c.good << '\t' << alt
-                             << '\t' << c.path.size() << '\t' << c.uniques << '\t'
-                             << (ham ? 'T' : 'F') << '\t' << path_string(c.path, g_)
+                        out_ << path_counter << '\t' << c->bad << '\t' << c->good << '\t' << alt
+                             << '\t' << c->path.size() << '\t' << c->uniques << '\t'
+                             << (ham ? 'T' : 'F') << '\t' << path_string(c->path, g_)
                              << std::endl;
                 }
             }
@@ -259,16 +263,15 @@ public:
     uint64_t batches() const { return batches_; }
 
 private:
-    struct Child {
+    // A candidate path: a queue entry, or a pre-generated extension of one.
+    struct Node {
         std::vector<Step> path;
-        int record = -1;          // node-table record of the node stepped onto
+        std::vector<uint32_t> budget;   // per node-table record, as the entry would
+                                        // carry it in the queue (include/alignments.h:26)
         uint32_t uniques = 0, bad = 0, good = 0;
-    };
-    struct Entry {
-        std::vector<Step> path;
-        std::vector<uint32_t> budget;   // per node-table record (include/alignments.h:26)
-        std::vector<Child> children;
-        bool expanded = false;
+        bool at_destination = false;
+        bool kids_made = false, kids_scored = false;
+        std::vector<std::unique_ptr<Node>> kids;   // extensions, adjacency order
     };
     struct Key {
         int32_t alt;
@@ -279,49 +282,71 @@ private:
         }
     };
 
-    // Extensions of one queue entry, in adjacency order (:136-151).
-    void make_children(Entry &e) const
+    // Extensions of one entry, in adjacency order (:136-151, :165-167).
+    void make_kids(Node &e) const
     {
+        e.kids_made = true;
         const Step last = e.path.back();
         for (const Edge &v : g_.adjacency[(size_t)last.id]) {
             if (last.orientation != '0' && last.orientation != v.from_orient) continue;   // :137
             const int rec = record_of_[v.to];
             if (rec < 0 || e.budget[(size_t)rec] == 0) continue;                          // :142-143
-            Child c;
-            c.path = e.path;
-            if (c.path.back().orientation == '0') c.path.back().orientation = v.from_orient;
-            c.path.push_back({(int32_t)v.to, v.to_orient});
-            c.record = rec;
-            c.uniques = count_uniques(c.path);
-            e.children.push_back(std::move(c));
+            auto c = std::make_unique<Node>();
+            c->path = e.path;
+            if (c->path.back().orientation == '0') c->path.back().orientation = v.from_orient;
+            c->path.push_back({(int32_t)v.to, v.to_orient});
+            c->uniques = count_uniques(c->path);
+            c->at_destination = v.to == dest_uid_;
+            if (!c->at_destination) {
+                c->budget = e.budget;
+                --c->budget[(size_t)rec];
+            }
+            e.kids.push_back(std::move(c));
         }
     }
 
-    // Score the children of the front entry together with those of the next
-    // best entries that have not been expanded yet (speculation; see header).
+    // Generate and score, in one batch, the unscored part of the subtrees under
+    // the best queue entries (front first), breadth-first.
     bool expand_front()
     {
-        std::vector<Entry *> todo;
-        for (auto it = queue_.begin(); it != queue_.end() && todo.size() < opt_.speculate; ++it)
-            if (!it->second->expanded) todo.push_back(it->second.get());
+        std::vector<Node *> level, parents;   // parents: nodes whose kids get scored now
         std::vector<int32_t> off{0}, steps;
-        for (Entry *e : todo) {
-            make_children(*e);
-            for (Child &c : e->children) {
-                for (const Step &s : c.path) steps.push_back(pack(s));
-                off.push_back((int32_t)steps.size());
+        size_t n_paths = 0;
+        auto it = queue_.begin();
+        // roots: the front entry always; further entries while there is room
+        while (it != queue_.end() && (level.empty() || n_paths + level.size() < opt_.speculate / 4)) {
+            level.push_back(it->second.get());
+            ++it;
+            if (level.size() >= 64) break;
+        }
+        while (!level.empty() && n_paths < opt_.speculate) {
+            std::vector<Node *> next;
+            for (Node *e : level) {
+                if (n_paths >= opt_.speculate && e != queue_.begin()->second.get()) break;
+                if (!e->kids_made) {
+                    make_kids(*e);
+                    parents.push_back(e);
+                    for (auto &c : e->kids) {
+                        for (const Step &s : c->path) steps.push_back(pack(s));
+                        off.push_back((int32_t)steps.size());
+                        ++n_paths;
+                    }
+                }
+                for (auto &c : e->kids)
+                    if (!c->at_destination && c->path.size() < GFAL_MAX_STEPS) next.push_back(c.get());
             }
+            level.swap(next);
         }
         std::vector<uint32_t> bad, good;
         if (!scorer_.score(off, steps, true, bad, good)) return false;   // :162
         size_t k = 0;
-        for (Entry *e : todo) {
-            for (Child &c : e->children) {
-                c.bad = bad[k];
-                c.good = good[k];
+        for (Node *e : parents) {
+            for (auto &c : e->kids) {
+                c->bad = bad[k];
+                c->good = good[k];
                 ++k;
             }
-            e->expanded = true;
+            e->kids_scored = true;
         }
         scored_ += k;
         ++batches_;
@@ -332,9 +357,9 @@ private:
     PathScorer &scorer_;
     SearchOptions opt_;
     std::ostream &out_;
-    const NodeTable *table_ = nullptr;
+    uint32_t dest_uid_ = 0;
     std::vector<int> record_of_;
-    std::map<Key, std::unique_ptr<Entry>> queue_;
+    std::map<Key, std::unique_ptr<Node>> queue_;
     uint64_t seq_ = 0, scored_ = 0, batches_ = 0;
 };
 
