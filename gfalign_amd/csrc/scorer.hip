@@ -139,6 +139,7 @@ __global__ __launch_bounds__(WAVE) void k_prep(
     extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
     uint16_t *img = smem;
     uint16_t *lids = smem + L.total;   // nm entries: local node id per step
+    uint32_t *head32 = reinterpret_cast<uint32_t *>(smem + L.total + L.nm);   // v2 chain heads
     const int p = blockIdx.x;
     const int lane = threadIdx.x;
     if (p >= n_paths) return;
@@ -157,10 +158,13 @@ __global__ __launch_bounds__(WAVE) void k_prep(
     uint32_t *next = reinterpret_cast<uint32_t *>(img + L.next_at());
     uint16_t *step = img + L.step_at();
     uint16_t *rstep = img + L.rstep_at();
-    for (int i = lane; i < L.total; i += WAVE) img[i] = (uint16_t)ENT_NONE;
-    __syncthreads();
-    for (int i = lane; i < NEXT_CAP; i += WAVE) next[i] = ENT_NONE;
-    __syncthreads();
+    {   // 0xFFFF everywhere (32-bit stores), then the 32-bit chain entries
+        uint32_t *img32 = reinterpret_cast<uint32_t *>(img);
+        for (int i = lane; i < L.total / 2; i += WAVE) img32[i] = 0xFFFFFFFFu;
+        __syncthreads();
+        for (int i = lane; i < NEXT_CAP; i += WAVE) next[i] = ENT_NONE;
+        __syncthreads();
+    }
 
     bool id_ok = true;
     for (int i = lane; i < n; i += WAVE) {
@@ -184,42 +188,47 @@ __global__ __launch_bounds__(WAVE) void k_prep(
         rstep[i] = (uint16_t)(code == STEP_NOMATCH ? STEP_NOMATCH : (code ^ 1u));
     }
 
-    // Occurrence chains in increasing position order: walk the path backwards.
-    // Steps that equal nothing (STEP_NOMATCH) are left out of the chains; a
-    // node that only has such steps gets ENT_PRESENT (it still passes the
-    // filter).  Bit 15 of lids[] marks the last occurrence of each node.
-    // Lane l owns the nodes with lid % 64 == l: every lane walks the whole
-    // path (uniform LDS reads) and updates only its own chains, so the 64
-    // lanes build disjoint chains concurrently.
-    for (int i = n - 1; i >= 0; --i) {
-        const uint32_t lid = lids[i];
-        if (lid == ENT_NONE || (int)(lid & 63u) != lane) continue;
-        const uint32_t head = first[lid];
-        if (head == ENT_NONE) lids[i] = (uint16_t)(lid | 0x8000u);
-        const uint32_t code = step[i];
-        if (code == STEP_NOMATCH) {
-            if (head == ENT_NONE) first[lid] = (uint16_t)ENT_PRESENT;
-            continue;
+    // Occurrence chains, built by all lanes at once: every matchable position
+    // swaps itself into its node's chain head (LDS atomic exchange) and keeps
+    // the previous head as its successor.  The order of a chain is whatever the
+    // hardware made it; the search ORs over all occurrences, so any order gives
+    // the same answer.  Steps that equal nothing (STEP_NOMATCH) stay out of the
+    // chains; a node that only has such steps gets ENT_PRESENT (it still passes
+    // the filter).  Exactly one position per node sees an empty head: it stands
+    // for the node in the `unaligned` sum below.
+    for (int i = lane; i < L.v2; i += WAVE) head32[i] = ENT_NONE;
+    __syncthreads();
+    uint32_t covered = 0;
+    for (int base = 0; base < n; base += WAVE) {
+        const int i = base + lane;
+        const uint32_t lid = i < n ? (uint32_t)lids[i] : ENT_NONE;
+        const uint32_t code = i < n ? (uint32_t)step[i] : STEP_NOMATCH;
+        if (lid != ENT_NONE && code != STEP_NOMATCH) {
+            const uint32_t ent = (uint32_t)i | ((code & 1u) ? ENT_NEG : 0u);
+            const uint32_t old = atomicExch(&head32[lid], ent);
+            next[i] = old;
+            // unaligned (src/eval.cpp:83-88) = steps of all alignments whose
+            // node is not on the path = total - sum over the distinct path
+            // nodes of how many alignment steps carry them
+            if (filter && old == ENT_NONE) covered += node_hist[lid];
         }
-        next[i] = head == ENT_PRESENT ? ENT_NONE : head;
-        first[lid] = (uint16_t)((uint32_t)i | ((code & 1u) ? ENT_NEG : 0u));
     }
+    __syncthreads();
+    for (int base = 0; base < n; base += WAVE) {
+        const int i = base + lane;
+        const uint32_t lid = i < n ? (uint32_t)lids[i] : ENT_NONE;
+        if (lid != ENT_NONE && step[i] == STEP_NOMATCH) {
+            const uint32_t old = atomicCAS(&head32[lid], ENT_NONE, ENT_PRESENT);
+            if (filter && old == ENT_NONE) covered += node_hist[lid];
+        }
+    }
+    __syncthreads();
+    for (int i = lane; i < L.v2; i += WAVE) first[i] = (uint16_t)head32[i];
     if (lane == 0) {
         img[L.len_at()] = (uint16_t)n;
         img[L.len_at() + 1] = 0;
     }
     __syncthreads();
-
-    // unaligned (src/eval.cpp:83-88) = steps of all alignments whose node is
-    // not on the path = total - sum over the distinct path nodes of how many
-    // alignment steps carry them.
-    uint32_t covered = 0;
-    if (filter) {
-        for (int i = lane; i < n; i += WAVE) {
-            const uint32_t lid = lids[i];
-            if (lid != ENT_NONE && (lid & 0x8000u)) covered += node_hist[lid & 0x7FFFu];
-        }
-    }
 
     uint16_t *dst = images + (size_t)p * L.total;
     for (int i = lane * 2; i < L.total; i += WAVE * 2)
@@ -1390,7 +1399,8 @@ int gfal_scorer_score_device(gfal_scorer *s, const int32_t *d_path_off,
     hipEvent_t *ev = s->ev[s->ev_calls % gfal_scorer::EV_RING];
     if (s->profiling) HIP_TRY(hipEventRecord(ev[0], st));
 
-    const size_t prep_lds = img_bytes + (size_t)L.nm * sizeof(uint16_t);
+    const size_t prep_lds = img_bytes + (size_t)L.nm * sizeof(uint16_t) +
+                            (size_t)L.v2 * sizeof(uint32_t);
     hipLaunchKernelGGL(k_prep, dim3((unsigned)n_paths), dim3(WAVE), prep_lds, st,
                        d_path_off, d_path_steps, (int)n_paths, total_steps,
                        (int)max_path_len, s->d_node_local, (int)s->n_nodes,
@@ -1602,7 +1612,8 @@ int gfal_scorer_pair_scores(gfal_scorer *s, const int32_t *path_steps, int32_t n
     HIP_TRY(hipMemcpy(s->d_path_steps, path_steps, (size_t)n * sizeof(int32_t),
                       hipMemcpyHostToDevice));
     HIP_TRY(hipMemsetAsync(s->d_status, 0, 2 * sizeof(uint32_t), s->stream));
-    const size_t prep_lds = img_bytes + (size_t)L.nm * sizeof(uint16_t);
+    const size_t prep_lds = img_bytes + (size_t)L.nm * sizeof(uint16_t) +
+                            (size_t)L.v2 * sizeof(uint32_t);
     hipLaunchKernelGGL(k_prep, dim3(1), dim3(WAVE), prep_lds, s->stream, s->d_path_off,
                        s->d_path_steps, 1, (int64_t)n, (int)n, s->d_node_local,
                        (int)s->n_nodes, s->d_node_hist, (uint32_t)s->n_steps,
