@@ -29,6 +29,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -253,8 +254,7 @@ struct ScanArgs {
     int n_paths;
     int tile;                 // paths per workgroup (<= MAX_TILE)
     int n_tiles;
-    int n_chunks;             // multiple of 8
-    int items_per_chunk;
+    int n_chunks;
     int filter;
     uint32_t *counts;         // bad[P] | good[P] | unaligned[P]
     unsigned long long *worklist;
@@ -626,14 +626,15 @@ __global__ __launch_bounds__(SCAN_THREADS, 6) void k_scan(ScanArgs a)
     const int lane = tid & (WAVE - 1);
     const int wave = tid >> 6;
 
-    // Workgroups b and b+8 share an XCD (observed round-robin dispatch): keep
-    // every tile of one alignment chunk on one XCD so the chunk stays in that
-    // XCD's L2.  Speed only -- any placement gives the same counters.
+    // (tile, chunk) <- workgroup id, tile-major.  A chunk is a strided subset of
+    // the items (chunk, chunk + n_chunks, ...): items are ordered by alignment
+    // length, so contiguous ranges would give the workgroups of the last chunks
+    // all the long, expensive alignments.  (Pinning chunks to XCDs for L2
+    // locality was measured slower for the same reason: the XCD with the long
+    // alignments finishes last.)
     const int bid = blockIdx.x;
-    const int xcd = bid & 7;
-    const int within = bid >> 3;
-    const int tile_id = within % a.n_tiles;
-    const int chunk = (within / a.n_tiles) * 8 + xcd;
+    const int tile_id = bid % a.n_tiles;
+    const int chunk = bid / a.n_tiles;
 
     TileView tv;
     tv.path0 = tile_id * a.tile;
@@ -674,9 +675,8 @@ __global__ __launch_bounds__(SCAN_THREADS, 6) void k_scan(ScanArgs a)
     __syncthreads();
 
     WaveCounts wc;                        // lane p: path0 + p
-    const int item_begin = chunk * a.items_per_chunk;
-    const int item_end = min(item_begin + a.items_per_chunk, a.items.n_items);
-    for (int it = item_begin + wave; it < item_end; it += SCAN_WAVES) {
+    for (int it = chunk + wave * a.n_chunks; it < a.items.n_items;
+         it += SCAN_WAVES * a.n_chunks) {
         const int M = __builtin_amdgcn_readfirstlane((int)a.items.len[it]);
         const uint16_t *bp =
             a.items.steps + (size_t)a.items.base[it] * WAVE + lane;
@@ -1426,13 +1426,12 @@ int gfal_scorer_score_device(gfal_scorer *s, const int32_t *d_path_off,
         a.n_tiles = (n_paths + tile - 1) / tile;
         // enough workgroups to fill 256 CUs x 2 several times over, but every
         // chunk keeps a few items per wave
-        const int want_groups = 4096;
+        int want_groups = 8192;
+        if (const char *env = getenv("GFAL_SCAN_GROUPS")) want_groups = std::max(1, atoi(env));
         int chunks = (want_groups + a.n_tiles - 1) / a.n_tiles;
         const int max_chunks = std::max(1, s->n_items / (2 * SCAN_WAVES));
         chunks = std::max(1, std::min(chunks, max_chunks));
-        chunks = (chunks + 7) & ~7;
         a.n_chunks = chunks;
-        a.items_per_chunk = (s->n_items + chunks - 1) / chunks;
         a.filter = filter ? 1 : 0;
         a.counts = d_counts;
         a.worklist = s->d_worklist;
