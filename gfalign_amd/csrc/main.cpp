@@ -209,7 +209,9 @@ int run_eval_path(const Options &o, const Graph &g, const std::vector<GafRecord>
     PackedAlignments packed;
     for (auto &r : recs) packed.add(r, g);
     PathScorer scorer;
-    if (!scorer.open(packed, (int32_t)g.headers.size(), o.device)) return 1;
+    std::vector<int32_t> universe;
+    for (auto &s : path) universe.push_back(s.id);
+    if (!scorer.open(packed, (int32_t)g.headers.size(), o.device, universe)) return 1;
 
     std::cout << path_string(path, g) << std::endl;                       // :72-73
     std::vector<int32_t> pst;
@@ -445,8 +447,21 @@ int main(int argc, char **argv)
             fprintf(stderr, "Error: source or destination not in graph.\n");
             return EXIT_FAILURE;
         }
+        // nodes the search can step on: the node list (include/nodetable.h:16-43)
+        // plus source and destination (src/eval.cpp:127-128)
+        std::vector<int32_t> universe{(int32_t)g.ids.at(o.source),
+                                      (int32_t)g.ids.at(o.destination)};
+        {
+            std::ifstream nf(o.node_file);
+            std::string line;
+            while (std::getline(nf, line)) {
+                auto it = g.ids.find(split(line, '\t')[0]);
+                if (it != g.ids.end()) universe.push_back((int32_t)it->second);
+            }
+        }
         PathScorer scorer;
-        if (!scorer.open(packed, (int32_t)g.headers.size(), o.device)) return EXIT_FAILURE;
+        if (!scorer.open(packed, (int32_t)g.headers.size(), o.device, universe))
+            return EXIT_FAILURE;
         SearchOptions so;
         so.node_file = o.node_file;
         so.source = o.source;

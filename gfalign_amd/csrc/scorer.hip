@@ -176,6 +176,10 @@ __global__ __launch_bounds__(WAVE) void k_prep(
         int32_t lid = -1;
         if (s < 0 || id >= n_nodes) id_ok = false;
         else lid = node_local[id];
+        if (lid == -2) {          // node outside the scorer's universe
+            id_ok = false;
+            lid = -1;
+        }
         step[i] = (uint16_t)((lid < 0 || other) ? STEP_NOMATCH
                                                  : (((uint32_t)lid << 1) | neg));
         lids[i] = (uint16_t)(lid < 0 ? ENT_NONE : (uint32_t)lid);
@@ -1184,10 +1188,19 @@ int gfal_scorer_create(const int32_t *aln_off, const int32_t *aln_steps,
                        int64_t n_aln, int32_t n_nodes, int device,
                        gfal_scorer **out)
 {
+    return gfal_scorer_create_ex(aln_off, aln_steps, n_aln, n_nodes, device, nullptr, 0, out);
+}
+
+int gfal_scorer_create_ex(const int32_t *aln_off, const int32_t *aln_steps,
+                          int64_t n_aln, int32_t n_nodes, int device,
+                          const int32_t *universe, int32_t n_universe,
+                          gfal_scorer **out)
+{
     if (!out) return GFAL_E_ARG;
     *out = nullptr;
     if (n_aln < 0 || n_nodes < 0 || (n_aln > 0 && (!aln_off || aln_off[0] != 0)))
         return GFAL_E_ARG;
+    if (n_universe < 0 || (n_universe > 0 && !universe)) return GFAL_E_ARG;
     if (n_aln >= (int64_t)1 << 31) return GFAL_E_RANGE;
     const int64_t S = n_aln ? aln_off[n_aln] : 0;
     if (S < 0 || (S > 0 && !aln_steps)) return GFAL_E_ARG;
@@ -1199,9 +1212,20 @@ int gfal_scorer_create(const int32_t *aln_off, const int32_t *aln_steps,
     }
 
     // ---- validate, find the nodes that occur, bucket by length ----
-    std::vector<int32_t> node_local((size_t)n_nodes, -1);
+    // node_local: >= 0 local id; -1 may be on a path but occurs in no
+    // alignment; -2 outside the universe (a path that steps on it is an error)
+    const bool has_universe = universe != nullptr;
+    std::vector<int32_t> node_local((size_t)n_nodes, has_universe ? -2 : -1);
+    for (int32_t u = 0; u < n_universe; ++u) {
+        if (universe[u] < 0 || universe[u] >= n_nodes) {
+            set_err("universe entry %d: node id out of range", u);
+            return GFAL_E_RANGE;
+        }
+        node_local[(size_t)universe[u]] = -1;
+    }
     int max_len = 0;
     uint32_t n_empty = 0;
+    bool any_outside = false;
     for (int64_t k = 0; k < n_aln; ++k) {
         int64_t m = (int64_t)aln_off[k + 1] - aln_off[k];
         if (m < 0 || aln_off[k + 1] > S) return GFAL_E_ARG;
@@ -1219,13 +1243,19 @@ int gfal_scorer_create(const int32_t *aln_off, const int32_t *aln_steps,
             set_err("alignment step %lld: node id out of range", (long long)t);
             return GFAL_E_RANGE;
         }
-        node_local[s >> 1] = 0;
+        if (node_local[s >> 1] == -1) node_local[s >> 1] = 0;
+        else if (node_local[s >> 1] == -2) any_outside = true;
     }
     int n_local = 0;
     for (int32_t v = 0; v < n_nodes; ++v)
         if (node_local[v] == 0) node_local[v] = n_local++;
+    // every node outside the universe shares one local id: no path can carry
+    // it, so such steps only ever fail the filter / a comparison, and their
+    // histogram bin keeps `unaligned` exact
+    const int32_t outside_lid = any_outside ? n_local++ : -1;
     if (n_local > MAX_LOCAL_NODES) {
-        set_err("%d distinct nodes in the alignments; this build stages at most %d",
+        set_err("%d distinct nodes in the alignments; this build stages at most %d "
+                "(pass the nodes candidate paths can visit to gfal_scorer_create_ex)",
                 n_local, MAX_LOCAL_NODES);
         return GFAL_E_RANGE;
     }
@@ -1233,7 +1263,8 @@ int gfal_scorer_create(const int32_t *aln_off, const int32_t *aln_steps,
     std::vector<uint16_t> local_steps((size_t)S);
     for (int64_t t = 0; t < S; ++t) {
         int32_t s = aln_steps[t];
-        uint32_t lid = (uint32_t)node_local[s >> 1];
+        int32_t mapped = node_local[s >> 1];
+        uint32_t lid = (uint32_t)(mapped >= 0 ? mapped : outside_lid);
         ++hist[lid];
         local_steps[(size_t)t] = (uint16_t)((lid << 1) | ((uint32_t)s & 1u));
     }

@@ -140,11 +140,15 @@ public:
     {
         if (h_) gfal_scorer_destroy(h_);
     }
-    bool open(const PackedAlignments &a, int32_t n_nodes, int device)
+    // universe: the nodes candidate paths may visit (node list + source +
+    // destination in search; the path's nodes in evalPath)
+    bool open(const PackedAlignments &a, int32_t n_nodes, int device,
+              const std::vector<int32_t> &universe)
     {
         n_aln_ = a.size();
         if (n_aln_ == 0) return true;
-        int rc = gfal_scorer_create(a.off.data(), a.steps.data(), n_aln_, n_nodes, device, &h_);
+        int rc = gfal_scorer_create_ex(a.off.data(), a.steps.data(), n_aln_, n_nodes, device,
+                                       universe.data(), (int32_t)universe.size(), &h_);
         if (rc != GFAL_OK) {
             fprintf(stderr, "Error: scorer: %s (%s)\n", gfal_strerror(rc), gfal_last_error());
             return false;

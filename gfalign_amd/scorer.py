@@ -37,6 +37,9 @@ EXPORTS = {
     "gfal_device_count": (ctypes.c_int, []),
     "gfal_scorer_create": (ctypes.c_int, [_i32p, _i32p, ctypes.c_int64, ctypes.c_int32,
                                           ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    "gfal_scorer_create_ex": (ctypes.c_int, [_i32p, _i32p, ctypes.c_int64, ctypes.c_int32,
+                                             ctypes.c_int, _i32p, ctypes.c_int32,
+                                             ctypes.POINTER(ctypes.c_void_p)]),
     "gfal_scorer_destroy": (None, [ctypes.c_void_p]),
     "gfal_scorer_score": (ctypes.c_int, [ctypes.c_void_p, _i32p, _i32p, ctypes.c_int32,
                                          ctypes.c_int, _u32p, _u32p, _u32p]),
@@ -110,14 +113,21 @@ def pack_step(node_id, orientation):
 class Scorer:
     """One shard of alignments resident on one MI355X."""
 
-    def __init__(self, aln_off, aln_steps, n_nodes, device=0):
+    def __init__(self, aln_off, aln_steps, n_nodes, device=0, universe=None):
         self._lib = load_library()
         self._h = ctypes.c_void_p()
         aln_off, aln_steps = _i32(aln_off), _i32(aln_steps)
         self.n_aln = len(aln_off) - 1
-        _check(self._lib.gfal_scorer_create(
-            _ptr(aln_off, ctypes.c_int32), _ptr(aln_steps, ctypes.c_int32),
-            self.n_aln, int(n_nodes), int(device), ctypes.byref(self._h)))
+        if universe is None:
+            _check(self._lib.gfal_scorer_create(
+                _ptr(aln_off, ctypes.c_int32), _ptr(aln_steps, ctypes.c_int32),
+                self.n_aln, int(n_nodes), int(device), ctypes.byref(self._h)))
+        else:
+            universe = _i32(universe)
+            _check(self._lib.gfal_scorer_create_ex(
+                _ptr(aln_off, ctypes.c_int32), _ptr(aln_steps, ctypes.c_int32),
+                self.n_aln, int(n_nodes), int(device),
+                _ptr(universe, ctypes.c_int32), len(universe), ctypes.byref(self._h)))
 
     def close(self):
         if self._h:

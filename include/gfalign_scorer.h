@@ -80,6 +80,20 @@ int gfal_scorer_create(const int32_t *aln_off, const int32_t *aln_steps,
                        int64_t n_aln, int32_t n_nodes, int device,
                        gfal_scorer **out);
 
+/*
+ * Same, with the set of nodes candidate paths may step on ("universe": in
+ * `gfalign search` the node list plus source and destination, src/eval.cpp:
+ * 126-128; in evalPath the nodes of the path).  Alignment nodes outside it can
+ * never be on a path, so they are folded into one id: results are identical,
+ * and a GAF over a whole assembly graph needs no more device tables than the
+ * tangle does.  universe == NULL means "any node" (gfal_scorer_create).  A
+ * later path that steps on a node outside the universe is GFAL_E_RANGE.
+ */
+int gfal_scorer_create_ex(const int32_t *aln_off, const int32_t *aln_steps,
+                          int64_t n_aln, int32_t n_nodes, int device,
+                          const int32_t *universe, int32_t n_universe,
+                          gfal_scorer **out);
+
 void gfal_scorer_destroy(gfal_scorer *s);
 
 /*

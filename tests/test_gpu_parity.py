@@ -190,3 +190,41 @@ def test_config2_sample_against_oracle(gpu):
         # batch composition must not matter
         b2, g2, u2 = sc.evaluate_paths(poff, pst, True)
         assert np.array_equal(b2, ebad) and np.array_equal(g2, egood) and np.array_equal(u2, euna)
+
+
+def test_universe_folds_outside_nodes(gpu):
+    """A GAF over a huge node space (more distinct nodes than the device tables
+    hold) scored against a small tangle: with the universe given, results are
+    identical to the oracle on the unreduced input."""
+    rnd = random.Random(31)
+    big = 200_000                              # node-id space
+    tangle = [rnd.randrange(big) for _ in range(40)]
+    walk = [(rnd.choice(tangle) << 1) | rnd.randrange(2) for _ in range(120)]
+    alns = []
+    for _ in range(3000):
+        m = rnd.randint(1, 9)
+        s0 = rnd.randrange(0, len(walk) - m)
+        b = list(walk[s0:s0 + m])
+        if rnd.random() < 0.5:                 # touches the rest of the genome
+            b[rnd.randrange(m)] = (rnd.randrange(big) << 1) | rnd.randrange(2)
+        if rnd.random() < 0.5:
+            b = [x ^ 1 for x in reversed(b)]
+        alns.append(b)
+    alns += [[(rnd.randrange(big) << 1)] for _ in range(40_000)]   # > 32766 distinct nodes
+    paths = [walk[:k] for k in (2, 17, 60, 120)] + [walk[5:50]]
+    aoff, ast = csr(alns)
+    poff, pst = csr(paths)
+    with pytest.raises(scorer.ScorerError) as e:
+        Scorer(aoff, ast, big)                 # no universe: too many nodes
+    assert e.value.code == -2
+    with Scorer(aoff, ast, big, universe=sorted(set(tangle))) as sc:
+        assert sc.info()["n_local_nodes"] <= len(set(tangle)) + 1
+        for flt in (True, False):
+            got = sc.evaluate_paths(poff, pst, flt)
+            exp = oracle.evaluate_paths(aoff, ast, poff, pst, flt)
+            for g, x in zip(got, exp):
+                assert np.array_equal(g, x), flt
+        outside = next(v for v in range(big) if v not in set(tangle))
+        with pytest.raises(scorer.ScorerError) as e:
+            sc.evaluate_paths([0, 2], [walk[0], outside << 1], True)
+        assert e.value.code == -2
