@@ -1,0 +1,17 @@
+#!/bin/bash
+# Run on the GPU box (gpurun):  bash scripts/collect_profiles.sh <round-tag>
+# Writes rocprofv3 output under gpurun_out/prof_<tag>_*; scripts/save_profiles.py
+# then condenses it into profiles/.
+tag=${1:-r01}
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
+B="python3 bench.py --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_stats -- $B --steps 20 --warmup 3 > gpurun_out/prof_${tag}_stats.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof_${tag}_fetch -- $B --steps 3 --warmup 1 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof_${tag}_write -- $B --steps 3 --warmup 1 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d gpurun_out/prof_${tag}_tcc -- $B --steps 3 --warmup 1 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_BRANCH --output-format csv -d gpurun_out/prof_${tag}_sq1 -- $B --steps 3 --warmup 1 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d gpurun_out/prof_${tag}_sq2 -- $B --steps 3 --warmup 1 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/prof_${tag}_grbm -- $B --steps 3 --warmup 1 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof_${tag}_calib -- ./tools/fetch_calib > gpurun_out/prof_${tag}_calib.log 2>&1
+python3 bench.py --steps 20 --warmup 3 > gpurun_out/bench_${tag}_full.json 2> gpurun_out/bench_${tag}_full.err
+tail -c 600 gpurun_out/bench_${tag}_full.json
