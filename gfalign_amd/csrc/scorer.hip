@@ -41,7 +41,9 @@ namespace {
 constexpr int WAVE = 64;
 constexpr int SCAN_THREADS = 768;
 constexpr int SCAN_WAVES = SCAN_THREADS / WAVE;
-constexpr int MAX_REG_M = 16;          // alignments up to this length live in VGPRs
+constexpr int MAX_REG_K = 16;          // alignments of up to 2K+1 = 33 steps are compared
+                                       // from registers (K pair dwords per lane)
+constexpr int MAX_REG_M = 16;          // smallest step-array capacity of an image
 constexpr int MAX_TILE = 32;           // one bit per tile path in the node masks
 constexpr int LDS_BUDGET = 80 * 1024;  // two workgroups per CU (160 KiB LDS)
 constexpr int DP_THREADS = 64;
@@ -56,7 +58,7 @@ constexpr uint32_t ENT_PRESENT = 0xFFFEu;  // node is on the path, but only as
 constexpr uint32_t ENT_POS = 0x03FFu;      // position in the path (0..999)
 constexpr uint32_t ENT_NEG = 0x8000u;      // step there is '-'
 constexpr int NEXT_CAP = 1024;             // next[] is indexable by any ENT_POS value
-constexpr int NEVER_LEN = 32;              // uint16 entries of the never-matching window
+constexpr int NEVER_LEN = 40;              // uint16 entries of the never-matching window
 constexpr uint32_t STEP_NOMATCH = 0xFFFEu; // path step that equals nothing
 constexpr uint32_t STEP_INVALID = 0xFFFFu; // padding lane of an item
 constexpr int MAX_LOCAL_NODES = 32766;     // 2*V-1 must stay below STEP_NOMATCH
@@ -111,17 +113,22 @@ ImageLayout make_layout(int n_local, int max_len)
 {
     ImageLayout L;
     L.v2 = (n_local + 1) & ~1;
-    L.nm = std::max((max_len + 3) & ~1, 2 * MAX_REG_M);
+    L.nm = std::max((max_len + 5) & ~1, 2 * MAX_REG_M);   // windows read up to n + 3
     L.total = (L.len_at() + 2 + 7) & ~7;
     return L;
 }
 
 // Items: 64 alignments of equal length m, step-major.  Step t of lane l of
 // item k sits at steps[item_base[k] * 64 + t * 64 + l].
+// pairs[item_pbase[k] * 64 + j * 64 + l] = step 2j+1 | step 2j+2 << 16 of lane l:
+// the steps after the first, two to a dword, as the scan kernel compares them
+// (m / 2 dwords per lane; the upper half of the last one is 0 when m is even).
 struct Items {
     const uint16_t *steps;
     const uint32_t *base;   // per item, in units of 64 uint16
     const uint16_t *len;    // per item, m
+    const uint32_t *pairs;
+    const uint32_t *pbase;  // per item, in units of 64 uint32
     int n_items;
 };
 
@@ -387,16 +394,22 @@ struct ChainView {
 };
 
 // pairs[k] = b[1 + 2k] | b[2 + 2k] << 16: steps 1..M-1 two to a dword.
-template <int M>
-__device__ __forceinline__ lanemask subpath_search(const uint32_t (&pairs)[(M / 2) ? (M / 2) : 1],
+// K = M / 2 is a template constant; M itself (2K or 2K + 1) is the template
+// constant MC when that is non-zero (short alignments: everything folds at
+// compile time) and the wave-uniform run-time value otherwise.
+template <int K, int MC>
+__device__ __forceinline__ lanemask subpath_search(const uint32_t (&pairs)[K ? K : 1], int M_rt,
                                                    uint32_t o0, uint32_t e,
                                                    const ChainView &cv)
 {
-    constexpr int K = M / 2;          // dwords of alignment steps to compare
-    constexpr int KD = (M + 1) / 2;   // dwords of path steps that cover them
+    const int M = MC ? MC : M_rt;
+    // dwords of path steps that cover the K pairs at either alignment
+    constexpr int KD = MC ? (MC + 1) / 2 : K + 1;
     bool found = false;
     const uint32_t last_start = (uint32_t)(cv.n - M);
     const uint32_t n1 = (uint32_t)(cv.n - 1);
+    // M even: the last pair holds one step only
+    const uint32_t last_mask = (M & 1) ? 0xFFFFFFFFu : 0x0000FFFFu;
     while (true) {
         const uint32_t pos = e & ENT_POS;
         // same orientation as b0: B may start at pos of the path; opposite:
@@ -410,7 +423,7 @@ __device__ __forceinline__ lanemask subpath_search(const uint32_t (&pairs)[(M / 
         idx = fits ? idx : 2u * cv.nm;
         const uint32_t nx = cv.next[pos];
         bool ok = fits;
-        if (M > 1) {
+        if (K > 0) {
             const uint32_t *wd = cv.step32 + (idx >> 1);
             const uint32_t sh = idx << 4;          // alignbit uses bits 4:0: 0 or 16
             uint32_t d[KD];
@@ -418,12 +431,16 @@ __device__ __forceinline__ lanemask subpath_search(const uint32_t (&pairs)[(M / 
             for (int k = 0; k < KD; ++k) d[k] = wd[k];
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                const uint32_t hi = d[(k + 1 < KD) ? k + 1 : k];
-                const uint32_t got = __builtin_amdgcn_alignbit(hi, d[k], sh);
-                if (2 * k + 2 < M)
+                const uint32_t got =
+                    __builtin_amdgcn_alignbit(d[(k + 1 < KD) ? k + 1 : k], d[k], sh);
+                if (k + 1 < K)
                     ok &= got == pairs[k];
-                else        // last pair holds one step only
+                else if (MC && !(MC & 1))   // compile-time even M: one step in the last pair
                     ok &= (uint16_t)got == (uint16_t)pairs[k];
+                else if (MC)
+                    ok &= got == pairs[k];
+                else
+                    ok &= ((got ^ pairs[k]) & last_mask) == 0u;
             }
         }
         found |= ok;
@@ -463,36 +480,41 @@ __device__ __forceinline__ lanemask subpath_search_long(const uint16_t *__restri
     return WAVE_MASK(found);
 }
 
-// One item against the tile: M is the template constant and b[] holds the
-// steps of the wave's 64 alignments.
-template <int M>
+// One item against the tile.  K = M / 2 pair dwords per lane live in
+// registers; M (wave-uniform) is 2K or 2K + 1, a compile-time constant MC for
+// short alignments (MC = 0: run-time).
+template <int K, int MC>
 __device__ __forceinline__ void scan_item(const ScanArgs &a, const TileView &tv,
-                                          const uint16_t *__restrict__ bp, int lane,
+                                          const uint16_t *__restrict__ bp,
+                                          const uint32_t *__restrict__ pp, int M_rt, int lane,
                                           uint32_t slot, WaveCounts &wc)
 {
-    uint32_t b[M];
+    const int M = MC ? MC : M_rt;
+    uint32_t b0 = bp[0];
+    uint32_t pairs[K ? K : 1];
+    pairs[0] = 0;
 #pragma unroll
-    for (int t = 0; t < M; ++t) b[t] = bp[t * WAVE];
-    const bool valid = b[0] != STEP_INVALID;
+    for (int k = 0; k < K; ++k) pairs[k] = pp[k * WAVE];
+    const bool valid = b0 != STEP_INVALID;
     if (!valid) {           // keep table indices in range on padding lanes
+        b0 = 0;
 #pragma unroll
-        for (int t = 0; t < M; ++t) b[t] = 0;
+        for (int k = 0; k < K; ++k) pairs[k] = 0;
     }
     // bit p of pass: every node of this alignment occurs on tile path p, i.e.
     // the alignment survives the filter of src/eval.cpp:81-91 for that path
     uint32_t pass = valid ? tv.all_paths : 0u;
     if (a.filter) {
+        pass &= tv.nodemask[b0 >> 1];
 #pragma unroll
-        for (int t = 0; t < M; ++t) pass &= tv.nodemask[b[t] >> 1];
+        for (int k = 0; k < K; ++k) {
+            pass &= tv.nodemask[(pairs[k] & 0xFFFFu) >> 1];
+            if (k + 1 < K || (M & 1)) pass &= tv.nodemask[pairs[k] >> 17];
+        }
     }
     // the head lookup reads first[] (uint16 entries) through a dword
-    const uint32_t node0_word = b[0] >> 2, node0_shift = (b[0] & 2u) << 3;
-    const uint32_t o0 = (b[0] & 1u) << 15;
-    uint32_t pairs[(M / 2) ? (M / 2) : 1];
-    pairs[0] = 0;
-#pragma unroll
-    for (int k = 0; k < M / 2; ++k)
-        pairs[k] = b[1 + 2 * k] | ((2 * k + 2 < M) ? (b[2 + 2 * k] << 16) : 0u);
+    const uint32_t node0_word = b0 >> 2, node0_shift = (b0 & 2u) << 3;
+    const uint32_t o0 = (b0 & 1u) << 15;
     // positions of the path's first step inside B, refreshed when a0 changes
     uint32_t cached_a0 = 0xFFFFFFFFu, a0_fw = 0, a0_rc = 0;
     lanemask a0_any = 0;    // lanes with a0_fw | a0_rc != 0
@@ -520,7 +542,7 @@ __device__ __forceinline__ void scan_item(const ScanArgs &a, const TileView &tv,
 #endif
         const uint32_t head = (img32[node0_word] >> node0_shift) & 0xFFFFu;
         const uint32_t e = in ? head : ENT_NONE;
-        const lanemask found_m = subpath_search<M>(pairs, o0, e, cv);
+        const lanemask found_m = subpath_search<K, MC>(pairs, M, o0, e, cv);
         const lanemask open_m = in_m & ~found_m;
         lanemask bad_m = 0;
         if (open_m != 0) {
@@ -530,13 +552,20 @@ __device__ __forceinline__ void scan_item(const ScanArgs &a, const TileView &tv,
             const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)tv.hdr_a0, p);
             if (a0 != cached_a0) {
                 cached_a0 = a0;
+                // bit t-1 of a0_fw: b[t] == a0 (t >= 1); bit t of a0_rc: b[t]^1 == a0 (t <= M-2)
                 a0_fw = 0;
-                a0_rc = 0;
+                a0_rc = (M >= 2 && (b0 ^ 1u) == a0) ? 1u : 0u;
 #pragma unroll
-                for (int t = 1; t < M; ++t) a0_fw |= (b[t] == a0) ? (1u << t) : 0u;
-#pragma unroll
-                for (int t = 0; t < M - 1; ++t)
-                    a0_rc |= ((b[t] ^ 1u) == a0) ? (1u << t) : 0u;
+                for (int k = 0; k < K; ++k) {
+                    const uint32_t lo = pairs[k] & 0xFFFFu, hi = pairs[k] >> 16;
+                    const int t_lo = 2 * k + 1, t_hi = 2 * k + 2;
+                    a0_fw |= (lo == a0) ? (1u << (t_lo - 1)) : 0u;
+                    a0_rc |= (t_lo <= M - 2 && (lo ^ 1u) == a0) ? (1u << t_lo) : 0u;
+                    if (t_hi < M) {
+                        a0_fw |= (hi == a0) ? (1u << (t_hi - 1)) : 0u;
+                        a0_rc |= (t_hi <= M - 2 && (hi ^ 1u) == a0) ? (1u << t_hi) : 0u;
+                    }
+                }
                 a0_any = WAVE_MASK((a0_fw | a0_rc) != 0u);
             }
             const lanemask maybe_m = open_m & a0_any;
@@ -544,13 +573,11 @@ __device__ __forceinline__ void scan_item(const ScanArgs &a, const TileView &tv,
             if (maybe_m != 0) {
                 const bool open = (open_m >> lane) & 1ull;
                 bool cand_fw = false, cand_rc = false;
-#pragma unroll
                 for (int t = 1; t < M; ++t) {      // B[t..M) == path[0..M-t) ?
-                    const bool live = open && ((a0_fw >> t) & 1u);
+                    const bool live = open && ((a0_fw >> (t - 1)) & 1u);
                     if (WAVE_ANY(live))
                         cand_fw |= tail_equals(bp, t, 1, M - t, 0u, step32, live);
                 }
-#pragma unroll
                 for (int t = 0; t < M - 1; ++t) {  // rc(B)[M-1-t..M) == path[0..t+1) ?
                     const bool live = open && ((a0_rc >> t) & 1u);
                     if (WAVE_ANY(live))
@@ -685,18 +712,30 @@ __global__ __launch_bounds__(SCAN_THREADS, 6) void k_scan(ScanArgs a)
         const uint16_t *bp =
             a.items.steps + (size_t)a.items.base[it] * WAVE + lane;
         const uint32_t slot = (uint32_t)it * WAVE + lane;
+        const uint32_t *pp = a.items.pairs + (size_t)a.items.pbase[it] * WAVE + lane;
+        if (M > 2 * MAX_REG_K + 1) {
+            scan_item_long(a, tv, bp, M, lane, slot, wc);
+            continue;
+        }
         switch (M) {
 #define GFAL_CASE(MM)                                                          \
     case MM:                                                                   \
-        scan_item<MM>(a, tv, bp, lane, slot, wc);                              \
+        scan_item<MM / 2, MM>(a, tv, bp, pp, M, lane, slot, wc);               \
         break;
             GFAL_CASE(1) GFAL_CASE(2) GFAL_CASE(3) GFAL_CASE(4)
             GFAL_CASE(5) GFAL_CASE(6) GFAL_CASE(7) GFAL_CASE(8)
             GFAL_CASE(9) GFAL_CASE(10) GFAL_CASE(11) GFAL_CASE(12)
             GFAL_CASE(13) GFAL_CASE(14) GFAL_CASE(15) GFAL_CASE(16)
 #undef GFAL_CASE
-        default:
-            scan_item_long(a, tv, bp, M, lane, slot, wc);
+#define GFAL_CASE(KK)                                                          \
+    case 2 * KK:                                                               \
+    case 2 * KK + 1:                                                           \
+        scan_item<KK, 0>(a, tv, bp, pp, M, lane, slot, wc);                    \
+        break;
+            case 17: scan_item<8, 0>(a, tv, bp, pp, M, lane, slot, wc); break;
+            GFAL_CASE(9) GFAL_CASE(10) GFAL_CASE(11) GFAL_CASE(12)
+            GFAL_CASE(13) GFAL_CASE(14) GFAL_CASE(15) GFAL_CASE(16)
+#undef GFAL_CASE
         }
     }
 
@@ -1067,6 +1106,8 @@ struct gfal_scorer {
     uint16_t *d_item_steps = nullptr;
     uint32_t *d_item_base = nullptr;
     uint16_t *d_item_len = nullptr;
+    uint32_t *d_item_pairs = nullptr;
+    uint32_t *d_item_pbase = nullptr;
     int32_t *d_slot_orig = nullptr;    // [n_items*64] original index or -1
     uint32_t *d_status = nullptr;      // [2]: status word, worklist count
     unsigned long long *d_worklist = nullptr;   // as pushed by k_scan
@@ -1125,7 +1166,8 @@ void free_scorer(gfal_scorer *s)
 {
     if (!s) return;
     (void)hipSetDevice(s->device);
-    void *bufs[] = {s->d_node_local, s->d_node_hist, s->d_item_steps, s->d_item_base,
+    void *bufs[] = {s->d_item_pairs, s->d_item_pbase,
+                    s->d_node_local, s->d_node_hist, s->d_item_steps, s->d_item_base,
                     s->d_item_len,   s->d_slot_orig, s->d_status,     s->d_worklist,
                     s->d_worklist_sorted, s->d_wl_bins,
                     s->d_rows,       s->d_images,    s->d_path_off,   s->d_path_steps,
@@ -1279,6 +1321,7 @@ int gfal_scorer_create_ex(const int32_t *aln_off, const int32_t *aln_steps,
     std::vector<uint16_t> item_steps;
     std::vector<uint32_t> item_base;
     std::vector<uint16_t> item_len;
+    std::vector<uint32_t> item_pairs, item_pbase;
     std::vector<int32_t> slot_orig;
     item_steps.reserve((size_t)S + 64 * 64);
     for (int m = 1; m <= max_len; ++m) {
@@ -1297,11 +1340,19 @@ int gfal_scorer_create_ex(const int32_t *aln_off, const int32_t *aln_steps,
             item_base.push_back((uint32_t)(base / WAVE));
             item_len.push_back((uint16_t)m);
             item_steps.resize(base + (size_t)m * WAVE, (uint16_t)STEP_INVALID);
+            const size_t pbase = item_pairs.size();
+            const int K = m / 2;
+            item_pbase.push_back((uint32_t)(pbase / WAVE));
+            item_pairs.resize(pbase + (size_t)K * WAVE, 0xFFFFFFFFu);
             for (size_t l = 0; l < WAVE; ++l) {
                 if (l < cnt) {
                     const uint16_t *px = ls + aln_off[idx[at + l]];
                     for (int t = 0; t < m; ++t)
                         item_steps[base + (size_t)t * WAVE + l] = px[t];
+                    for (int k = 0; k < K; ++k)
+                        item_pairs[pbase + (size_t)k * WAVE + l] =
+                            (uint32_t)px[2 * k + 1] |
+                            ((2 * k + 2 < m) ? ((uint32_t)px[2 * k + 2] << 16) : 0u);
                     slot_orig.push_back(idx[at + l]);
                 } else {
                     slot_orig.push_back(-1);
@@ -1355,6 +1406,8 @@ int gfal_scorer_create_ex(const int32_t *aln_off, const int32_t *aln_steps,
     if ((rc = dev_upload(&s->d_item_steps, item_steps))) return fail(rc);
     if ((rc = dev_upload(&s->d_item_base, item_base))) return fail(rc);
     if ((rc = dev_upload(&s->d_item_len, item_len))) return fail(rc);
+    if ((rc = dev_upload(&s->d_item_pairs, item_pairs))) return fail(rc);
+    if ((rc = dev_upload(&s->d_item_pbase, item_pbase))) return fail(rc);
     if ((rc = dev_upload(&s->d_slot_orig, slot_orig))) return fail(rc);
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_status), 2 * sizeof(uint32_t)));
     CREATE_TRY(hipMemset(s->d_status, 0, 2 * sizeof(uint32_t)));
@@ -1445,7 +1498,8 @@ int gfal_scorer_score_device(gfal_scorer *s, const int32_t *d_path_off,
     s->last_lds = 0;
     if (s->n_items > 0) {
         ScanArgs a;
-        a.items = Items{s->d_item_steps, s->d_item_base, s->d_item_len, s->n_items};
+        a.items = Items{s->d_item_steps, s->d_item_base, s->d_item_len, s->d_item_pairs,
+                        s->d_item_pbase, s->n_items};
         a.images = s->d_images;
         a.L = L;
         a.n_paths = n_paths;
@@ -1666,7 +1720,8 @@ int gfal_scorer_pair_scores(gfal_scorer *s, const int32_t *path_steps, int32_t n
     hipLaunchKernelGGL(k_fill_i32, dim3(fill_blocks), dim3(256), 0, s->stream, d_rc,
                        (long long)s->n_aln, 0);
     if (s->n_items > 0) {
-        Items items{s->d_item_steps, s->d_item_base, s->d_item_len, s->n_items};
+        Items items{s->d_item_steps, s->d_item_base, s->d_item_len, s->d_item_pairs,
+                    s->d_item_pbase, s->n_items};
         if (dp_rows_fit_lds(s->max_aln_len))
             hipLaunchKernelGGL(k_pairs<true>, dim3(DP_BLOCKS), dim3(DP_THREADS),
                                dp_lds_bytes(s->max_aln_len), s->stream, items,
