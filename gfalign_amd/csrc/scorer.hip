@@ -271,7 +271,7 @@ struct ScanArgs {
     unsigned long long *worklist;
     uint32_t *wl_count;
     uint32_t wl_capacity;
-    uint32_t *wl_hist;        // [4 * n_paths] entries per (path, length class)
+    uint32_t *wl_hist;        // [N_CLASSES * n_paths] entries per (length class, path)
     uint32_t *status;
 };
 
@@ -280,11 +280,12 @@ struct ScanArgs {
 constexpr unsigned long long WL_FW = 1ull << 62, WL_RC = 1ull << 63;
 constexpr uint32_t WL_PATH_MASK = 0x3FFFFFFFu;
 
-// Length classes of the DP kernel (rows held in 8 / 16 / 32 registers, or in
-// LDS / HBM for longer alignments).
+// Length classes of the DP kernels (rows held in 4 / 8 / 16 / 32 registers, or
+// in LDS / HBM for longer alignments).
+constexpr int N_CLASSES = 5, LONG_CLASS = 4;
 __host__ __device__ __forceinline__ int length_class(int m)
 {
-    return m <= 8 ? 0 : m <= 16 ? 1 : m <= 32 ? 2 : 3;
+    return m <= 4 ? 0 : m <= 8 ? 1 : m <= 16 ? 2 : m <= 32 ? 3 : LONG_CLASS;
 }
 
 // What a wave keeps about the tile while it walks its items.
@@ -973,7 +974,7 @@ __device__ __forceinline__ void class_range(const uint32_t *offsets, int n_paths
                                             uint32_t total, uint32_t &lo, uint32_t &hi)
 {
     lo = min(offsets[cls * n_paths], total);
-    hi = cls == 3 ? total : min(offsets[(cls + 1) * n_paths], total);
+    hi = cls == LONG_CLASS ? total : min(offsets[(cls + 1) * n_paths], total);
 }
 
 struct DpArgs {
@@ -1013,7 +1014,7 @@ __device__ __forceinline__ DpEntry load_entry(const DpArgs &a, uint32_t w, bool 
     return e;
 }
 
-// Length classes 0..2: rows in MC registers.
+// Length classes 0..3: rows in MC registers.
 template <int MC, int CLS>
 __global__ __launch_bounds__(DP_THREADS) void k_dp_regs(DpArgs a)
 {
@@ -1030,7 +1031,7 @@ __global__ __launch_bounds__(DP_THREADS) void k_dp_regs(DpArgs a)
     }
 }
 
-// Length class 3 (more than 32 steps): rows in LDS or HBM.
+// Last length class (more than 32 steps): rows in LDS or HBM.
 template <bool ROWS_IN_LDS>
 __global__ __launch_bounds__(DP_THREADS) void k_dp_long(DpArgs a)
 {
@@ -1038,7 +1039,7 @@ __global__ __launch_bounds__(DP_THREADS) void k_dp_long(DpArgs a)
     uint32_t *row = dp_row<ROWS_IN_LDS>(a.row_scratch, stride);
     const uint32_t total = min(*a.wl_count, a.wl_capacity);
     uint32_t lo, hi;
-    class_range(a.offsets, a.n_paths, 3, total, lo, hi);
+    class_range(a.offsets, a.n_paths, LONG_CLASS, total, lo, hi);
     const uint32_t n_threads = gridDim.x * DP_THREADS;
     for (uint32_t w0 = lo + blockIdx.x * DP_THREADS; w0 < hi; w0 += n_threads) {
         const uint32_t w = w0 + threadIdx.x;
@@ -1113,7 +1114,7 @@ struct gfal_scorer {
     unsigned long long *d_worklist = nullptr;   // as pushed by k_scan
     unsigned long long *d_worklist_sorted = nullptr;
     uint32_t wl_capacity = 0;
-    uint32_t *d_wl_bins = nullptr;     // [3][4 * n_paths]: hist | offsets | cursor
+    uint32_t *d_wl_bins = nullptr;     // [3][N_CLASSES * n_paths]: hist | offsets | cursor
     size_t wl_bins_cap = 0;
     uint32_t *d_rows = nullptr;        // DP row scratch
     uint16_t *d_images = nullptr;
@@ -1467,14 +1468,14 @@ int gfal_scorer_score_device(gfal_scorer *s, const int32_t *d_path_off,
             int rc = dev_reserve(&s->d_images, &s->images_cap, want);
             if (rc) return rc;
         }
-        size_t bins = (size_t)3 * 4 * n_paths;
+        size_t bins = (size_t)3 * N_CLASSES * n_paths;
         if (bins > s->wl_bins_cap) {
             if (s->have_last) HIP_TRY(hipStreamSynchronize(s->last_stream));
             int rc = dev_reserve(&s->d_wl_bins, &s->wl_bins_cap, bins);
             if (rc) return rc;
         }
     }
-    const int n_bins = 4 * n_paths;
+    const int n_bins = N_CLASSES * n_paths;
     uint32_t *d_hist = s->d_wl_bins, *d_offsets = s->d_wl_bins + n_bins,
              *d_cursor = s->d_wl_bins + 2 * (size_t)n_bins;
     HIP_TRY(hipMemsetAsync(d_hist, 0, (size_t)n_bins * sizeof(uint32_t), st));
@@ -1550,11 +1551,13 @@ int gfal_scorer_score_device(gfal_scorer *s, const int32_t *d_path_off,
         d.wl_capacity = s->wl_capacity;
         d.row_scratch = s->d_rows;
         d.counts = d_counts;
-        hipLaunchKernelGGL((k_dp_regs<8, 0>), dim3(DP_REG_BLOCKS), dim3(DP_THREADS), 0, st, d);
+        hipLaunchKernelGGL((k_dp_regs<4, 0>), dim3(DP_REG_BLOCKS), dim3(DP_THREADS), 0, st, d);
+        if (s->max_aln_len > 4)
+            hipLaunchKernelGGL((k_dp_regs<8, 1>), dim3(DP_REG_BLOCKS), dim3(DP_THREADS), 0, st, d);
         if (s->max_aln_len > 8)
-            hipLaunchKernelGGL((k_dp_regs<16, 1>), dim3(DP_REG_BLOCKS), dim3(DP_THREADS), 0, st, d);
+            hipLaunchKernelGGL((k_dp_regs<16, 2>), dim3(DP_REG_BLOCKS), dim3(DP_THREADS), 0, st, d);
         if (s->max_aln_len > 16)
-            hipLaunchKernelGGL((k_dp_regs<32, 2>), dim3(DP_REG_BLOCKS), dim3(DP_THREADS), 0, st, d);
+            hipLaunchKernelGGL((k_dp_regs<32, 3>), dim3(DP_REG_BLOCKS), dim3(DP_THREADS), 0, st, d);
         if (s->max_aln_len > 32) {
             if (dp_rows_fit_lds(s->max_aln_len))
                 hipLaunchKernelGGL(k_dp_long<true>, dim3(DP_BLOCKS), dim3(DP_THREADS),
