@@ -55,6 +55,8 @@ constexpr int DP_REG_BLOCKS = 4096;   // register-row kernels: 4 waves per SIMD
 constexpr uint32_t ENT_NONE = 0xFFFFu;     // no (further) occurrence
 constexpr uint32_t ENT_PRESENT = 0xFFFEu;  // node is on the path, but only as
                                            // steps that equal nothing
+constexpr uint32_t ENT_FOUND = 0xFFFDu;    // scan kernel: this lane's search ended in a
+                                           // match (next[1021] points back at it)
 constexpr uint32_t ENT_POS = 0x03FFu;      // position in the path (0..999)
 constexpr uint32_t ENT_NEG = 0x8000u;      // step there is '-'
 constexpr int NEXT_CAP = 1024;             // next[] is indexable by any ENT_POS value
@@ -170,7 +172,8 @@ __global__ __launch_bounds__(WAVE) void k_prep(
         uint32_t *img32 = reinterpret_cast<uint32_t *>(img);
         for (int i = lane; i < L.total / 2; i += WAVE) img32[i] = 0xFFFFFFFFu;
         __syncthreads();
-        for (int i = lane; i < NEXT_CAP; i += WAVE) next[i] = ENT_NONE;
+        for (int i = lane; i < NEXT_CAP; i += WAVE)
+            next[i] = i == (int)(ENT_FOUND & ENT_POS) ? ENT_FOUND : ENT_NONE;
         __syncthreads();
     }
 
@@ -365,7 +368,7 @@ struct WaveCounts {
     __device__ __forceinline__ void add(int p, int lane, lanemask good_m, lanemask bad_m)
     {
         const uint32_t inc = (uint32_t)__popcll(good_m) | ((uint32_t)__popcll(bad_m) << 16);
-        packed += (lane == p) ? inc : 0u;
+        if (lane == p) packed += inc;
     }
     __device__ __forceinline__ void flush()
     {
@@ -406,7 +409,6 @@ __device__ __forceinline__ lanemask subpath_search(const uint32_t (&pairs)[K ? K
     const int M = MC ? MC : M_rt;
     // dwords of path steps that cover the K pairs at either alignment
     constexpr int KD = MC ? (MC + 1) / 2 : K + 1;
-    bool found = false;
     const uint32_t last_start = (uint32_t)(cv.n - M);
     const uint32_t n1 = (uint32_t)(cv.n - 1);
     // M even: the last pair holds one step only
@@ -417,7 +419,7 @@ __device__ __forceinline__ lanemask subpath_search(const uint32_t (&pairs)[K ? K
         // B may start at n-1-pos of its reverse complement
         const bool rc = (e & ENT_NEG) != o0;
         const uint32_t start = rc ? n1 - pos : pos;
-        // terminal entries decode to pos 1023/1022: start > n - M either way
+        // terminal entries decode to pos >= 1021: start > n - M either way
         const bool fits = start <= last_start;
         // uint16 index of the first step to compare (step 1 of the window)
         uint32_t idx = start + (rc ? cv.nm + 1u : 1u);
@@ -425,7 +427,7 @@ __device__ __forceinline__ lanemask subpath_search(const uint32_t (&pairs)[K ? K
         const uint32_t nx = cv.next[pos];
         bool ok = fits;
         if (K > 0) {
-            const uint32_t *wd = cv.step32 + (idx >> 1);
+            const uint32_t *wd = cv.step32 + ((idx & ~1u) >> 1);
             const uint32_t sh = idx << 4;          // alignbit uses bits 4:0: 0 or 16
             uint32_t d[KD];
 #pragma unroll
@@ -444,18 +446,18 @@ __device__ __forceinline__ lanemask subpath_search(const uint32_t (&pairs)[K ? K
                     ok &= ((got ^ pairs[k]) & last_mask) == 0u;
             }
         }
-        found |= ok;
-        e = ok ? ENT_NONE : nx;     // next[1022..1023] hold ENT_NONE
-        if (!WAVE_ANY(e < ENT_PRESENT)) break;
+        // a matched lane parks on ENT_FOUND (next[1021] == ENT_FOUND keeps it
+        // there); exhausted chains park on ENT_NONE (next[1022..1023])
+        e = ok ? ENT_FOUND : nx;
+        if (!WAVE_ANY(e < ENT_FOUND)) break;
     }
-    return WAVE_MASK(found);
+    return WAVE_MASK(e == ENT_FOUND);
 }
 
 __device__ __forceinline__ lanemask subpath_search_long(const uint16_t *__restrict__ bp,
                                                         int M, uint32_t b0, uint32_t e,
                                                         const ChainView &cv)
 {
-    bool found = false;
     const uint32_t o0 = (b0 & 1u) << 15;
     const uint32_t last_start = (uint32_t)(cv.n - M);
     const uint32_t n1 = (uint32_t)(cv.n - 1);
@@ -474,11 +476,10 @@ __device__ __forceinline__ lanemask subpath_search_long(const uint16_t *__restri
             const uint32_t at = fits ? idx + (uint32_t)t : idx;
             ok &= lds_u16(cv.step32, at) == (uint32_t)bp[t * WAVE];
         }
-        found |= ok;
-        e = ok ? ENT_NONE : nx;
-        if (!WAVE_ANY(e < ENT_PRESENT)) break;
+        e = ok ? ENT_FOUND : nx;
+        if (!WAVE_ANY(e < ENT_FOUND)) break;
     }
-    return WAVE_MASK(found);
+    return WAVE_MASK(e == ENT_FOUND);
 }
 
 // One item against the tile.  K = M / 2 pair dwords per lane live in
@@ -521,8 +522,7 @@ __device__ __forceinline__ void scan_item(const ScanArgs &a, const TileView &tv,
     lanemask a0_any = 0;    // lanes with a0_fw | a0_rc != 0
 
     for (int p = 0; p < tv.tile_paths; ++p) {
-        const bool in = ((pass >> p) & 1u) != 0u;
-        const lanemask in_m = WAVE_MASK(in);
+        const lanemask in_m = WAVE_MASK(((pass >> p) & 1u) != 0u);
         if (in_m == 0) continue;
         const int n = __builtin_amdgcn_readlane(tv.hdr_n, p);
         if (M > n) {                      // src/alignments.cpp:500 row-0 bound:
@@ -541,9 +541,10 @@ __device__ __forceinline__ void scan_item(const ScanArgs &a, const TileView &tv,
         wc.add(p, lane, in_m, 0);
         continue;
 #endif
+        // every lane searches (a lane that is not `in` misses a node of the
+        // path and cannot match; padding lanes are masked off right after)
         const uint32_t head = (img32[node0_word] >> node0_shift) & 0xFFFFu;
-        const uint32_t e = in ? head : ENT_NONE;
-        const lanemask found_m = subpath_search<K, MC>(pairs, M, o0, e, cv);
+        const lanemask found_m = subpath_search<K, MC>(pairs, M, o0, head, cv) & in_m;
         const lanemask open_m = in_m & ~found_m;
         lanemask bad_m = 0;
         if (open_m != 0) {
@@ -627,8 +628,7 @@ __device__ __forceinline__ void scan_item_long(const ScanArgs &a, const TileView
         cv.nm = (uint32_t)a.L.nm;
         cv.n = n;
         const uint32_t head = lds_u16(img32, b0 >> 1);
-        const uint32_t e = ((pass >> p) & 1u) ? head : ENT_NONE;
-        const lanemask found_m = subpath_search_long(bp, M, b0, e, cv);
+        const lanemask found_m = subpath_search_long(bp, M, b0, head, cv) & in_m;
         const lanemask open_m = in_m & ~found_m;
         lanemask bad_m = 0;
         if (open_m != 0) {
