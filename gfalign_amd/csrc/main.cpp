@@ -36,7 +36,7 @@ struct Options {
     uint32_t max_steps = 100000, min_nodes = 0;
     int return_all_paths = 0, cmd_flag = 0, stats_flag = 0, sort_alignment = 0;
     int terminal_alignments = 0;
-    int device = 0;
+    int device = 0, n_devices = 1;
 };
 
 int verbose_flag = 0;
@@ -211,7 +211,9 @@ int run_eval_path(const Options &o, const Graph &g, const std::vector<GafRecord>
     PathScorer scorer;
     std::vector<int32_t> universe;
     for (auto &s : path) universe.push_back(s.id);
-    if (!scorer.open(packed, (int32_t)g.headers.size(), o.device, universe)) return 1;
+    const bool share = getenv("GFALIGN_SHARE_DEVICE") != nullptr;
+    if (!scorer.open(packed, (int32_t)g.headers.size(), o.device, universe, o.n_devices, share))
+        return 1;
 
     std::cout << path_string(path, g) << std::endl;                       // :72-73
     std::vector<int32_t> pst;
@@ -219,15 +221,8 @@ int run_eval_path(const Options &o, const Graph &g, const std::vector<GafRecord>
     std::vector<int32_t> off{0, (int32_t)pst.size()};
     std::vector<uint32_t> bad, good;
     if (!scorer.score(off, pst, false, bad, good)) return 1;              // :238
-    std::vector<int32_t> fw((size_t)recs.size()), rc((size_t)recs.size());
-    if (scorer.n_aln() > 0) {
-        int err = gfal_scorer_pair_scores(scorer.handle(), pst.data(), (int32_t)pst.size(),
-                                          fw.data(), rc.data());
-        if (err != GFAL_OK) {
-            fprintf(stderr, "Error: scorer: %s (%s)\n", gfal_strerror(err), gfal_last_error());
-            return 1;
-        }
-    }
+    std::vector<int32_t> fw, rc;
+    if (!scorer.pair_scores(pst, fw, rc)) return 1;
     for (size_t k = 0; k < recs.size(); ++k) {                            // :100-102
         std::vector<Step> B;
         for (int32_t t = packed.off[k]; t < packed.off[k + 1]; ++t)
@@ -376,6 +371,7 @@ int main(int argc, char **argv)
         {"output-terminal-alignments", no_argument, &o.terminal_alignments, 1},
         {"min-nodes", required_argument, 0, 1},
         {"device", required_argument, 0, 2},
+        {"devices", required_argument, 0, 3},
         {"cmd", no_argument, &o.cmd_flag, 1},
         {"verbose", no_argument, &verbose_flag, 1},
         {"version", no_argument, 0, 'v'},
@@ -395,6 +391,7 @@ int main(int argc, char **argv)
         case 'j': break;
         case 1: o.min_nodes = (uint32_t)atoi(optarg); break;
         case 2: o.device = atoi(optarg); break;
+        case 3: o.n_devices = std::max(1, atoi(optarg)); break;
         case 'v':
             printf("gfalign v%s\n", VERSION);
             printf("Giulio Formenti giulio.formenti@gmail.com\n");
@@ -411,7 +408,8 @@ int main(int argc, char **argv)
             printf("--return-all-paths return all viable paths as they are discovered, not only "
                    "better ones (default: false).\n");
             printf("--min-nodes <int> do not report paths with less than int nodes (default: 0).\n");
-            printf("--device <int> HIP device to score on (default: 0).\n");
+            printf("--device <int> first HIP device to score on (default: 0).\n");
+            printf("--devices <int> shard the alignments over this many devices (default: 1).\n");
             return 0;
         default: break;
         }
@@ -460,7 +458,9 @@ int main(int argc, char **argv)
             }
         }
         PathScorer scorer;
-        if (!scorer.open(packed, (int32_t)g.headers.size(), o.device, universe))
+        const bool share = getenv("GFALIGN_SHARE_DEVICE") != nullptr;
+        if (!scorer.open(packed, (int32_t)g.headers.size(), o.device, universe, o.n_devices,
+                         share))
             return EXIT_FAILURE;
         SearchOptions so;
         so.node_file = o.node_file;

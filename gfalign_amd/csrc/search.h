@@ -18,6 +18,7 @@
 #include <memory>
 #include <set>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -132,49 +133,110 @@ struct PackedAlignments {
     int64_t size() const { return (int64_t)off.size() - 1; }
 };
 
-// Thin RAII wrapper; scoring with zero alignments never touches the device
-// (the loop of src/eval.cpp:80 has no iterations: all counters are zero).
+// The alignments, sharded over one or more MI355X: contiguous
+// ranges balanced by step count, one gfal_scorer per device; every device
+// scores the whole batch against its shard (one host thread each, so the
+// devices run concurrently) and the per-path integer counters are added up.
+// Scoring with zero alignments never touches a device (the loop of
+// src/eval.cpp:80 has no iterations: all counters are zero).
 class PathScorer {
 public:
     ~PathScorer()
     {
-        if (h_) gfal_scorer_destroy(h_);
+        for (gfal_scorer *h : shards_)
+            if (h) gfal_scorer_destroy(h);
     }
     // universe: the nodes candidate paths may visit (node list + source +
-    // destination in search; the path's nodes in evalPath)
-    bool open(const PackedAlignments &a, int32_t n_nodes, int device,
-              const std::vector<int32_t> &universe)
+    // destination in search; the path's nodes in evalPath).
+    // devices: first device and how many to use; share_device puts every shard
+    // on `first_device` (test rigs with one GPU).
+    bool open(const PackedAlignments &a, int32_t n_nodes, int first_device,
+              const std::vector<int32_t> &universe, int n_devices = 1,
+              bool share_device = false)
     {
         n_aln_ = a.size();
         if (n_aln_ == 0) return true;
-        int rc = gfal_scorer_create_ex(a.off.data(), a.steps.data(), n_aln_, n_nodes, device,
-                                       universe.data(), (int32_t)universe.size(), &h_);
-        if (rc != GFAL_OK) {
-            fprintf(stderr, "Error: scorer: %s (%s)\n", gfal_strerror(rc), gfal_last_error());
-            return false;
+        n_devices = (int)std::max<int64_t>(1, std::min<int64_t>(n_devices, n_aln_));
+        const int64_t total = a.off.back();
+        int64_t lo = 0;
+        for (int d = 0; d < n_devices; ++d) {
+            // first alignment whose start offset reaches this shard's share of the steps
+            const int64_t target = total * (d + 1) / n_devices;
+            int64_t hi = d + 1 == n_devices
+                             ? n_aln_
+                             : std::lower_bound(a.off.begin(), a.off.end(), (int32_t)target) -
+                                   a.off.begin();
+            hi = std::max(lo, std::min(hi, n_aln_));
+            std::vector<int32_t> off((size_t)(hi - lo) + 1);
+            for (int64_t k = lo; k <= hi; ++k) off[(size_t)(k - lo)] = a.off[(size_t)k] - a.off[(size_t)lo];
+            gfal_scorer *h = nullptr;
+            int rc = gfal_scorer_create_ex(off.data(), a.steps.data() + a.off[(size_t)lo], hi - lo,
+                                           n_nodes, share_device ? first_device : first_device + d,
+                                           universe.data(), (int32_t)universe.size(), &h);
+            if (rc != GFAL_OK) {
+                fprintf(stderr, "Error: scorer: %s (%s)\n", gfal_strerror(rc), gfal_last_error());
+                return false;
+            }
+            shards_.push_back(h);
+            shard_begin_.push_back(lo);
+            lo = hi;
         }
         return true;
     }
     bool score(const std::vector<int32_t> &off, const std::vector<int32_t> &steps, bool filter,
                std::vector<uint32_t> &bad, std::vector<uint32_t> &good)
     {
-        size_t P = off.size() - 1;
+        const size_t P = off.size() - 1;
         bad.assign(P, 0);
         good.assign(P, 0);
         if (n_aln_ == 0 || P == 0) return true;
-        int rc = gfal_scorer_score(h_, off.data(), steps.data(), (int32_t)P, filter ? 1 : 0,
-                                   bad.data(), good.data(), nullptr);
-        if (rc != GFAL_OK) {
-            fprintf(stderr, "Error: scorer: %s (%s)\n", gfal_strerror(rc), gfal_last_error());
-            return false;
+        const size_t D = shards_.size();
+        std::vector<std::vector<uint32_t>> pb(D, std::vector<uint32_t>(P)), pg(D, std::vector<uint32_t>(P));
+        std::vector<int> rcs(D, GFAL_OK);
+        std::vector<std::string> errs(D);
+        auto work = [&](size_t d) {
+            rcs[d] = gfal_scorer_score(shards_[d], off.data(), steps.data(), (int32_t)P,
+                                       filter ? 1 : 0, pb[d].data(), pg[d].data(), nullptr);
+            if (rcs[d] != GFAL_OK) errs[d] = gfal_last_error();
+        };
+        std::vector<std::thread> threads;
+        for (size_t d = 1; d < D; ++d) threads.emplace_back(work, d);
+        work(0);
+        for (auto &t : threads) t.join();
+        for (size_t d = 0; d < D; ++d) {
+            if (rcs[d] != GFAL_OK) {
+                fprintf(stderr, "Error: scorer: %s (%s)\n", gfal_strerror(rcs[d]), errs[d].c_str());
+                return false;
+            }
+            for (size_t k = 0; k < P; ++k) {
+                bad[k] += pb[d][k];
+                good[k] += pg[d][k];
+            }
         }
         return true;
     }
-    gfal_scorer *handle() { return h_; }
+    // fw / rc traceback scores of one path against every alignment, in input order
+    bool pair_scores(const std::vector<int32_t> &path, std::vector<int32_t> &fw,
+                     std::vector<int32_t> &rc)
+    {
+        fw.assign((size_t)n_aln_, 0);
+        rc.assign((size_t)n_aln_, 0);
+        for (size_t d = 0; d < shards_.size(); ++d) {
+            int err = gfal_scorer_pair_scores(shards_[d], path.data(), (int32_t)path.size(),
+                                              fw.data() + shard_begin_[d], rc.data() + shard_begin_[d]);
+            if (err != GFAL_OK) {
+                fprintf(stderr, "Error: scorer: %s (%s)\n", gfal_strerror(err), gfal_last_error());
+                return false;
+            }
+        }
+        return true;
+    }
     int64_t n_aln() const { return n_aln_; }
+    size_t n_shards() const { return shards_.size(); }
 
 private:
-    gfal_scorer *h_ = nullptr;
+    std::vector<gfal_scorer *> shards_;
+    std::vector<int64_t> shard_begin_;
     int64_t n_aln_ = 0;
 };
 

@@ -136,6 +136,11 @@ def test_eval_path_appendix_c2(cli, gpu):
                              REF_FILES + "/random3.gaf", "-p", gold["path"]])
     assert rc == 0, err
     assert out.splitlines() == gold["stdout"]
+    rc, out, err = run(cli, ["evalPath", "-f", REF_FILES + "/random3.gfa", "-g",
+                             REF_FILES + "/random3.gaf", "-p", gold["path"], "--devices", "2"],
+                       env={"GFALIGN_SHARE_DEVICE": "1"})
+    assert rc == 0, err
+    assert out.splitlines() == gold["stdout"]
 
 
 @pytest.mark.gpu
@@ -153,5 +158,9 @@ def test_search_on_a_synthetic_tangle_matches_oracle(cli, gpu, tmp_path):
         assert rc == 0, err
         outs.append(out)
     assert outs[0] == outs[1] == outs[2]          # batching never changes the output
+    # alignments sharded over three scorers (all on this box's one GPU): same bytes
+    rc, out, err = run(cli, base + ["--devices", "3"], env={"GFALIGN_SHARE_DEVICE": "1"})
+    assert rc == 0, err
+    assert out == outs[0]
     assert outs[0].splitlines() == exp
     assert any(int(r.split("\t")[2]) > 0 for r in exp[:-1])   # non-zero good counters
