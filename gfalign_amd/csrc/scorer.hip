@@ -957,7 +957,11 @@ __global__ __launch_bounds__(256) void k_wl_scatter(
     const uint32_t *__restrict__ offsets, uint32_t *__restrict__ cursor,
     uint32_t n_paths, unsigned long long *__restrict__ sorted)
 {
-    const uint32_t total = min(*wl_count, wl_capacity);
+    // overflow (status word set by k_scan): the histogram counted pairs that
+    // were never stored, so offsets do not describe the list; the call fails
+    // with GFAL_E_NOMEM and nothing downstream may touch the list
+    if (*wl_count > wl_capacity) return;
+    const uint32_t total = *wl_count;
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < total; w += stride) {
         const unsigned long long ent = worklist[w];
@@ -1018,7 +1022,8 @@ __device__ __forceinline__ DpEntry load_entry(const DpArgs &a, uint32_t w, bool 
 template <int MC, int CLS>
 __global__ __launch_bounds__(DP_THREADS) void k_dp_regs(DpArgs a)
 {
-    const uint32_t total = min(*a.wl_count, a.wl_capacity);
+    if (*a.wl_count > a.wl_capacity) return;     // overflow: see k_wl_scatter
+    const uint32_t total = *a.wl_count;
     uint32_t lo, hi;
     class_range(a.offsets, a.n_paths, CLS, total, lo, hi);
     const uint32_t n_threads = gridDim.x * DP_THREADS;
@@ -1037,7 +1042,8 @@ __global__ __launch_bounds__(DP_THREADS) void k_dp_long(DpArgs a)
 {
     int stride;
     uint32_t *row = dp_row<ROWS_IN_LDS>(a.row_scratch, stride);
-    const uint32_t total = min(*a.wl_count, a.wl_capacity);
+    if (*a.wl_count > a.wl_capacity) return;     // overflow: see k_wl_scatter
+    const uint32_t total = *a.wl_count;
     uint32_t lo, hi;
     class_range(a.offsets, a.n_paths, LONG_CLASS, total, lo, hi);
     const uint32_t n_threads = gridDim.x * DP_THREADS;
@@ -1414,6 +1420,8 @@ int gfal_scorer_create_ex(const int32_t *aln_off, const int32_t *aln_steps,
     CREATE_TRY(hipMemset(s->d_status, 0, 2 * sizeof(uint32_t)));
     // worklist: at least one entry per alignment, so a single path always fits
     s->wl_capacity = (uint32_t)std::max<int64_t>(n_aln, (int64_t)1 << 22);
+    if (const char *env = getenv("GFAL_DEBUG_WL_CAPACITY"))   // tests: force the overflow path
+        s->wl_capacity = (uint32_t)std::max<int64_t>(n_aln, atoll(env));
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_worklist),
                          (size_t)s->wl_capacity * sizeof(unsigned long long)));
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_worklist_sorted),

@@ -228,3 +228,23 @@ def test_universe_folds_outside_nodes(gpu):
         with pytest.raises(scorer.ScorerError) as e:
             sc.evaluate_paths([0, 2], [walk[0], outside << 1], True)
         assert e.value.code == -2
+
+
+def test_worklist_overflow_splits_the_batch(gpu, monkeypatch):
+    """More exact-DP pairs than the worklist holds: the blocking API halves the
+    batch until every piece fits (a single path always does)."""
+    rnd = random.Random(41)
+    alns, paths = random_case(rnd, 2, 2500, 64, 7, 10, min_m=2, min_n=4)
+    aoff, ast = csr(alns)
+    poff, pst = csr(paths)
+    monkeypatch.setenv("GFAL_DEBUG_WL_CAPACITY", "1")      # capacity = max(n_aln, 1)
+    with Scorer(aoff, ast, 4) as sc:
+        got = sc.evaluate_paths(poff, pst, True)
+        assert sc.info()["dp_pairs"] <= len(alns)            # the last piece fitted
+    monkeypatch.delenv("GFAL_DEBUG_WL_CAPACITY")
+    with Scorer(aoff, ast, 4) as sc:
+        sc.evaluate_paths(poff, pst, True)
+        assert sc.info()["dp_pairs"] > len(alns)             # unsplit, it would not have
+    exp = oracle.evaluate_paths(aoff, ast, poff, pst, True)
+    for g, x in zip(got, exp):
+        assert np.array_equal(g, x)
