@@ -299,7 +299,9 @@ int run_eval_gfa(const Options &o, std::vector<GafRecord> &recs, AlignmentTotals
                     }
                     pos = r->qend;
                 }
-                if (g2.size() == 2 && count == 1 && g2[0]->pend + 500 >= g2[0]->plen &&
+                // unsigned arithmetic as in the reference: pLen - 500 wraps for
+                // paths shorter than 500 (src/alignments.cpp:343)
+                if (g2.size() == 2 && count == 1 && g2[0]->pend >= g2[0]->plen - 500u &&
                     g2[1]->pstart <= 500) {
                     ++totals.terminal_supp;
                     if (o.terminal_alignments) std::cout << g2[0]->print() << g2[1]->print();
@@ -311,9 +313,10 @@ int run_eval_gfa(const Options &o, std::vector<GafRecord> &recs, AlignmentTotals
             prev = recs[k].qname;
         }
     }
+    // -g always sets alignStats_flag (src/main.cpp:310), so the summary is
+    // printed and the --sort-alignment output branch of
+    // src/input-gfalign.cpp:88-91 is never taken (validateFiles/test.2.tst)
     print_stats(totals, recs.size(), false);
-    if (o.sort_alignment)
-        for (auto &r : recs) std::cout << r.print();
     if (!o.out_file.empty()) {
         fprintf(stderr, "Error: evalGFA -o (RC:i edge tagging + GFA output) is not part of this "
                         "build.\n");

@@ -1031,7 +1031,10 @@ __global__ __launch_bounds__(DP_THREADS) void k_dp_regs(DpArgs a)
         const uint32_t w = w0 + threadIdx.x;
         const bool live = w < hi;
         const DpEntry e = load_entry(a, w, live);
-        const bool good = dp_decide_regs<MC>(e.astep, e.n, e.bp, e.m, e.has_fw, e.has_rc);
+        bool good = dp_decide_regs<MC>(e.astep, e.n, e.bp, e.m, e.has_fw, e.has_rc);
+#if defined(GFAL_ABLATE) && GFAL_ABLATE == 3
+        good = false;
+#endif
         if (live) atomicAdd(&a.counts[(good ? a.n_paths : 0) + e.p], 1u);
     }
 }

@@ -55,6 +55,17 @@ def test_reference_test7_filter(cli, tmp_path):
         assert (tmp_path / "gaf").read_text() == f.read()
 
 
+@pytest.mark.parametrize("name", ["test.0.tst", "test.2.tst", "test.3.tst", "test.5.tst"])
+def test_reference_evalgfa_summaries(cli, name):
+    """validateFiles/test.{0,2,3,5}.tst: evalGFA alignment summary on random1 /
+    random2, with and without --sort-alignment (test.1 / test.4 need the
+    gfastats report of the absent gfalibs and are out of scope)."""
+    args, expected = tst(name)
+    args = [a.replace("testFiles/", REF_FILES + "/") for a in args]
+    rc, out, _ = run(cli, args)
+    assert rc == 0 and out == expected
+
+
 def test_filter_min_nodes(cli, tmp_path):
     rc, out, _ = run(cli, ["filter", "-g", REF_FILES + "/random3.gaf", "-n",
                            REF_FILES + "/random3.filter_nodelist.ls", "-o", "x.gaf",
