@@ -45,7 +45,10 @@ constexpr int MAX_REG_K = 16;          // alignments of up to 2K+1 = 33 steps ar
                                        // from registers (K pair dwords per lane)
 constexpr int MAX_REG_M = 16;          // smallest step-array capacity of an image
 constexpr int MAX_TILE = 32;           // one bit per tile path in the node masks
-constexpr int LDS_BUDGET = 80 * 1024;  // two workgroups per CU (160 KiB LDS)
+constexpr int LDS_BUDGET = 80 * 1024;  // k_scan: two workgroups per CU (160 KiB LDS);
+                                       // one 160 KiB workgroup (twice the tile, 4 waves
+                                       // per SIMD) measured 19 % slower
+constexpr int LDS_MAX = 160 * 1024;
 constexpr int DP_THREADS = 64;
 constexpr int DP_BLOCKS = 512;        // row-scratch kernels (k_dp_long, k_pairs)
 constexpr int DP_REG_BLOCKS = 4096;   // register-row kernels: 4 waves per SIMD
@@ -1409,8 +1412,7 @@ int gfal_scorer_create_ex(const int32_t *aln_off, const int32_t *aln_steps,
                                    hipFuncAttributeMaxDynamicSharedMemorySize,
                                    LDS_BUDGET));
     CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_prep),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   LDS_BUDGET + 2 * (GFAL_MAX_STEPS + 2)));
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
     if ((rc = dev_upload(&s->d_node_local, node_local))) return fail(rc);
     if ((rc = dev_upload(&s->d_node_hist, hist))) return fail(rc);
     if ((rc = dev_upload(&s->d_item_steps, item_steps))) return fail(rc);
