@@ -398,6 +398,9 @@ struct ChainView {
     const uint32_t *step32;   // step[nm] | rstep[nm] | never[NEVER_LEN]
     uint32_t nm;
     int n;
+#if defined(GFAL_ABLATE) && GFAL_ABLATE == 4
+    uint32_t *dbg;
+#endif
 };
 
 // pairs[k] = b[1 + 2k] | b[2 + 2k] << 16: steps 1..M-1 two to a dword.
@@ -417,6 +420,16 @@ __device__ __forceinline__ lanemask subpath_search(const uint32_t (&pairs)[K ? K
     // M even: the last pair holds one step only
     const uint32_t last_mask = (M & 1) ? 0xFFFFFFFFu : 0x0000FFFFu;
     while (true) {
+#if defined(GFAL_ABLATE) && GFAL_ABLATE == 4
+        {
+            const uint32_t e1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)e);
+            const bool uni = __builtin_amdgcn_ballot_w64(e == e1 && o0 == (uint32_t)__builtin_amdgcn_readfirstlane((int)o0)) == __builtin_amdgcn_ballot_w64(true);
+            if ((threadIdx.x & 63) == 0) {
+                atomicAdd(cv.dbg, 1u);
+                if (uni) atomicAdd(cv.dbg + 1, 1u);
+            }
+        }
+#endif
         const uint32_t pos = e & ENT_POS;
         // same orientation as b0: B may start at pos of the path; opposite:
         // B may start at n-1-pos of its reverse complement
@@ -540,6 +553,9 @@ __device__ __forceinline__ void scan_item(const ScanArgs &a, const TileView &tv,
         cv.step32 = step32;
         cv.nm = (uint32_t)a.L.nm;
         cv.n = n;
+#if defined(GFAL_ABLATE) && GFAL_ABLATE == 4
+        cv.dbg = a.status + 2;
+#endif
 #if defined(GFAL_ABLATE) && GFAL_ABLATE == 2
         wc.add(p, lane, in_m, 0);
         continue;
@@ -1122,7 +1138,7 @@ struct gfal_scorer {
     uint32_t *d_item_pairs = nullptr;
     uint32_t *d_item_pbase = nullptr;
     int32_t *d_slot_orig = nullptr;    // [n_items*64] original index or -1
-    uint32_t *d_status = nullptr;      // [2]: status word, worklist count
+    uint32_t *d_status = nullptr;      // [4]: status word, worklist count, 2 debug words
     unsigned long long *d_worklist = nullptr;   // as pushed by k_scan
     unsigned long long *d_worklist_sorted = nullptr;
     uint32_t wl_capacity = 0;
@@ -1421,8 +1437,8 @@ int gfal_scorer_create_ex(const int32_t *aln_off, const int32_t *aln_steps,
     if ((rc = dev_upload(&s->d_item_pairs, item_pairs))) return fail(rc);
     if ((rc = dev_upload(&s->d_item_pbase, item_pbase))) return fail(rc);
     if ((rc = dev_upload(&s->d_slot_orig, slot_orig))) return fail(rc);
-    CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_status), 2 * sizeof(uint32_t)));
-    CREATE_TRY(hipMemset(s->d_status, 0, 2 * sizeof(uint32_t)));
+    CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_status), 4 * sizeof(uint32_t)));
+    CREATE_TRY(hipMemset(s->d_status, 0, 4 * sizeof(uint32_t)));
     // worklist: at least one entry per alignment, so a single path always fits
     s->wl_capacity = (uint32_t)std::max<int64_t>(n_aln, (int64_t)1 << 22);
     if (const char *env = getenv("GFAL_DEBUG_WL_CAPACITY"))   // tests: force the overflow path
@@ -1493,7 +1509,7 @@ int gfal_scorer_score_device(gfal_scorer *s, const int32_t *d_path_off,
              *d_cursor = s->d_wl_bins + 2 * (size_t)n_bins;
     HIP_TRY(hipMemsetAsync(d_hist, 0, (size_t)n_bins * sizeof(uint32_t), st));
 
-    HIP_TRY(hipMemsetAsync(s->d_status, 0, 2 * sizeof(uint32_t), st));
+    HIP_TRY(hipMemsetAsync(s->d_status, 0, 4 * sizeof(uint32_t), st));
     hipEvent_t *ev = s->ev[s->ev_calls % gfal_scorer::EV_RING];
     if (s->profiling) HIP_TRY(hipEventRecord(ev[0], st));
 
@@ -1780,11 +1796,14 @@ int gfal_scorer_get_info(gfal_scorer *s, gfal_info *out)
     out->lds_bytes = s->last_lds;
     if (s->have_last) {
         HIP_TRY(hipSetDevice(s->device));
-        uint32_t host[2] = {0, 0};
+        uint32_t host[4] = {0, 0, 0, 0};
         HIP_TRY(hipMemcpyAsync(host, s->d_status, sizeof(host), hipMemcpyDeviceToHost,
                                s->last_stream));
         HIP_TRY(hipStreamSynchronize(s->last_stream));
         out->dp_pairs = host[1];
+#if defined(GFAL_ABLATE) && GFAL_ABLATE == 4
+        fprintf(stderr, "chain-loop iterations %u, with a wave-uniform entry %u\n", host[2], host[3]);
+#endif
         if (s->profiling && s->ev_calls > 0) {
             const int n = std::min(s->ev_calls, (int)gfal_scorer::EV_RING);
             double scan = 0, dp = 0, total = 0;
