@@ -248,3 +248,28 @@ def test_worklist_overflow_splits_the_batch(gpu, monkeypatch):
     exp = oracle.evaluate_paths(aoff, ast, poff, pst, True)
     for g, x in zip(got, exp):
         assert np.array_equal(g, x)
+
+
+@pytest.mark.parametrize("n", [33, 64, 998, 999, 1000])
+def test_windows_at_the_ends_of_the_path(gpu, n):
+    """Alignments of every register-resident length (and just beyond) cut from
+    the very start and the very end of the path, both strands, exact and with
+    one step changed: exercises the dword window reads next to the array ends."""
+    rnd = random.Random(50 + n)
+    path = [(rnd.randrange(120) << 1) | rnd.randrange(2) for _ in range(n)]
+    alns = []
+    for m in list(range(1, 36)) + [40]:
+        if m > n:
+            continue
+        for piece in (path[:m], path[n - m:], path[1:1 + m], path[n - m - 1:n - 1]):
+            if len(piece) != m:
+                continue
+            alns.append(list(piece))
+            alns.append([x ^ 1 for x in reversed(piece)])
+            bad = list(piece)
+            bad[-1] ^= 1
+            alns.append(bad)
+            bad = list(piece)
+            bad[0] = (121 << 1)
+            alns.append(bad)
+    check(alns, [path, path[:n - 1], path[1:]], 128)
