@@ -1,5 +1,5 @@
 """Condense gpurun_out/prof_<tag>_* (scripts/collect_profiles.sh) into profiles/."""
-import collections, csv, glob, json, shutil, sys
+import collections, csv, glob, json, os, shutil, sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 KEYS = ("k_scan", "k_dp_regs<8", "k_dp_regs<16", "k_dp_regs<32", "k_dp_long", "k_prep",
@@ -8,7 +8,9 @@ KEYS = ("k_scan", "k_dp_regs<8", "k_dp_regs<16", "k_dp_regs<32", "k_dp_long", "k
 
 def summ(d):
     out = {}
-    for f in glob.glob("gpurun_out/prof_%s_%s/*/*_counter_collection.csv" % (tag, d)):
+    files = sorted(glob.glob("gpurun_out/prof_%s_%s/*/*_counter_collection.csv" % (tag, d)),
+                   key=os.path.getmtime)[-1:]      # newest run only
+    for f in files:
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
             n = r["Kernel_Name"]
@@ -23,7 +25,8 @@ def summ(d):
     return out
 
 
-stats = glob.glob("gpurun_out/prof_%s_stats/*/*_kernel_stats.csv" % tag)[0]
+stats = sorted(glob.glob("gpurun_out/prof_%s_stats/*/*_kernel_stats.csv" % tag),
+               key=os.path.getmtime)[-1]
 shutil.copy(stats, "profiles/%s_bench_config3_kernel_stats.csv" % tag)
 pmc = {
     "_how": "scripts/collect_profiles.sh: one rocprofv3 --kernel-trace --pmc pass per counter "
