@@ -943,31 +943,45 @@ __device__ __forceinline__ bool dp_decide_regs(const uint16_t *__restrict__ aste
 // Counting sort of the worklist by (length class, path): each class becomes a
 // contiguous range for its own k_dp launch, and consecutive lanes share the
 // path (same n, same steps: broadcast loads).  Order only affects speed; any order gives the same counters.
+// hist / offsets / cursor are [N_CLASSES][n_paths].  Inside a class the bins are
+// laid out thread-strided (thread t owns paths t, t + 1024, ...: coalesced
+// loads); class_lo[c] is where class c starts, class_lo[N_CLASSES] the total.
 __global__ __launch_bounds__(1024) void k_wl_offsets(const uint32_t *__restrict__ hist,
                                                       uint32_t *__restrict__ offsets,
                                                       uint32_t *__restrict__ cursor,
-                                                      int n_bins)
+                                                      uint32_t *__restrict__ class_lo,
+                                                      int n_paths)
 {
     __shared__ uint32_t part[1024];
+    __shared__ uint32_t base;
     const int tid = threadIdx.x;
-    const int per = (n_bins + 1023) / 1024;
-    const int lo = min(tid * per, n_bins), hi = min(lo + per, n_bins);
-    uint32_t sum = 0;
-    for (int i = lo; i < hi; ++i) sum += hist[i];
-    part[tid] = sum;
+    if (tid == 0) base = 0;
     __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {      // Hillis-Steele inclusive scan
-        uint32_t v = tid >= o ? part[tid - o] : 0u;
+    for (int c = 0; c < N_CLASSES; ++c) {
+        const uint32_t *h = hist + (size_t)c * n_paths;
+        uint32_t sum = 0;
+        for (int p = tid; p < n_paths; p += 1024) sum += h[p];
+        part[tid] = sum;
         __syncthreads();
-        part[tid] += v;
+        for (int o = 1; o < 1024; o <<= 1) {      // Hillis-Steele inclusive scan
+            uint32_t v = tid >= o ? part[tid - o] : 0u;
+            __syncthreads();
+            part[tid] += v;
+            __syncthreads();
+        }
+        const uint32_t class_base = base;
+        uint32_t run = class_base + part[tid] - sum;
+        for (int p = tid; p < n_paths; p += 1024) {
+            offsets[(size_t)c * n_paths + p] = run;
+            cursor[(size_t)c * n_paths + p] = 0;
+            run += h[p];
+        }
+        if (tid == 0) class_lo[c] = class_base;
+        __syncthreads();
+        if (tid == 1023) base = class_base + part[1023];
         __syncthreads();
     }
-    uint32_t run = part[tid] - sum;
-    for (int i = lo; i < hi; ++i) {
-        offsets[i] = run;
-        cursor[i] = 0;
-        run += hist[i];
-    }
+    if (tid == 0) class_lo[N_CLASSES] = base;
 }
 
 __global__ __launch_bounds__(256) void k_wl_scatter(
@@ -993,11 +1007,11 @@ __global__ __launch_bounds__(256) void k_wl_scatter(
 }
 
 // Range of the sorted worklist that holds length class `cls`.
-__device__ __forceinline__ void class_range(const uint32_t *offsets, int n_paths, int cls,
-                                            uint32_t total, uint32_t &lo, uint32_t &hi)
+__device__ __forceinline__ void class_range(const uint32_t *class_lo, int cls, uint32_t total,
+                                            uint32_t &lo, uint32_t &hi)
 {
-    lo = min(offsets[cls * n_paths], total);
-    hi = cls == LONG_CLASS ? total : min(offsets[(cls + 1) * n_paths], total);
+    lo = min(class_lo[cls], total);
+    hi = min(class_lo[cls + 1], total);
 }
 
 struct DpArgs {
@@ -1006,7 +1020,7 @@ struct DpArgs {
     ImageLayout L;
     int n_paths;
     const unsigned long long *sorted;
-    const uint32_t *offsets;
+    const uint32_t *class_lo;   // [N_CLASSES + 1] ranges of the sorted list
     const uint32_t *wl_count;
     uint32_t wl_capacity;
     uint32_t *row_scratch;
@@ -1044,7 +1058,7 @@ __global__ __launch_bounds__(DP_THREADS) void k_dp_regs(DpArgs a)
     if (*a.wl_count > a.wl_capacity) return;     // overflow: see k_wl_scatter
     const uint32_t total = *a.wl_count;
     uint32_t lo, hi;
-    class_range(a.offsets, a.n_paths, CLS, total, lo, hi);
+    class_range(a.class_lo, CLS, total, lo, hi);
     const uint32_t n_threads = gridDim.x * DP_THREADS;
     for (uint32_t w0 = lo + blockIdx.x * DP_THREADS; w0 < hi; w0 += n_threads) {
         const uint32_t w = w0 + threadIdx.x;
@@ -1067,7 +1081,7 @@ __global__ __launch_bounds__(DP_THREADS) void k_dp_long(DpArgs a)
     if (*a.wl_count > a.wl_capacity) return;     // overflow: see k_wl_scatter
     const uint32_t total = *a.wl_count;
     uint32_t lo, hi;
-    class_range(a.offsets, a.n_paths, LONG_CLASS, total, lo, hi);
+    class_range(a.class_lo, LONG_CLASS, total, lo, hi);
     const uint32_t n_threads = gridDim.x * DP_THREADS;
     for (uint32_t w0 = lo + blockIdx.x * DP_THREADS; w0 < hi; w0 += n_threads) {
         const uint32_t w = w0 + threadIdx.x;
@@ -1497,7 +1511,7 @@ int gfal_scorer_score_device(gfal_scorer *s, const int32_t *d_path_off,
             int rc = dev_reserve(&s->d_images, &s->images_cap, want);
             if (rc) return rc;
         }
-        size_t bins = (size_t)3 * N_CLASSES * n_paths;
+        size_t bins = (size_t)3 * N_CLASSES * n_paths + 8;
         if (bins > s->wl_bins_cap) {
             if (s->have_last) HIP_TRY(hipStreamSynchronize(s->last_stream));
             int rc = dev_reserve(&s->d_wl_bins, &s->wl_bins_cap, bins);
@@ -1506,7 +1520,8 @@ int gfal_scorer_score_device(gfal_scorer *s, const int32_t *d_path_off,
     }
     const int n_bins = N_CLASSES * n_paths;
     uint32_t *d_hist = s->d_wl_bins, *d_offsets = s->d_wl_bins + n_bins,
-             *d_cursor = s->d_wl_bins + 2 * (size_t)n_bins;
+             *d_cursor = s->d_wl_bins + 2 * (size_t)n_bins,
+             *d_class_lo = s->d_wl_bins + 3 * (size_t)n_bins;
     HIP_TRY(hipMemsetAsync(d_hist, 0, (size_t)n_bins * sizeof(uint32_t), st));
 
     HIP_TRY(hipMemsetAsync(s->d_status, 0, 4 * sizeof(uint32_t), st));
@@ -1565,7 +1580,7 @@ int gfal_scorer_score_device(gfal_scorer *s, const int32_t *d_path_off,
         if (s->profiling) HIP_TRY(hipEventRecord(ev[2], st));
 
         hipLaunchKernelGGL(k_wl_offsets, dim3(1), dim3(1024), 0, st, d_hist, d_offsets,
-                           d_cursor, n_bins);
+                           d_cursor, d_class_lo, (int)n_paths);
         hipLaunchKernelGGL(k_wl_scatter, dim3(256), dim3(256), 0, st, a.items,
                            s->d_worklist, s->d_status + 1, s->wl_capacity, d_offsets,
                            d_cursor, (uint32_t)n_paths, s->d_worklist_sorted);
@@ -1575,7 +1590,7 @@ int gfal_scorer_score_device(gfal_scorer *s, const int32_t *d_path_off,
         d.L = L;
         d.n_paths = n_paths;
         d.sorted = s->d_worklist_sorted;
-        d.offsets = d_offsets;
+        d.class_lo = d_class_lo;
         d.wl_count = s->d_status + 1;
         d.wl_capacity = s->wl_capacity;
         d.row_scratch = s->d_rows;
