@@ -146,16 +146,18 @@ __global__ __launch_bounds__(WAVE) void k_prep(
     const int32_t *__restrict__ node_local, int n_nodes,
     const uint32_t *__restrict__ node_hist, uint32_t hist_total,
     uint32_t n_empty, int filter, ImageLayout L,
-    uint16_t *__restrict__ images, uint32_t *__restrict__ counts,
-    uint32_t *__restrict__ status)
+    const int32_t *__restrict__ order, uint16_t *__restrict__ images,
+    uint32_t *__restrict__ counts, uint32_t *__restrict__ status)
 {
     extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
     uint16_t *img = smem;
     uint16_t *lids = smem + L.total;   // nm entries: local node id per step
     uint32_t *head32 = reinterpret_cast<uint32_t *>(smem + L.total + L.nm);   // v2 chain heads
-    const int p = blockIdx.x;
+    // slot q of the image pool / of `counts` holds the q-th longest path
+    const int q = blockIdx.x;
     const int lane = threadIdx.x;
-    if (p >= n_paths) return;
+    if (q >= n_paths) return;
+    const int p = order ? order[q] : q;
 
     int64_t off = path_off[p];
     int64_t end = path_off[p + 1];
@@ -248,17 +250,81 @@ __global__ __launch_bounds__(WAVE) void k_prep(
     }
     __syncthreads();
 
-    uint16_t *dst = images + (size_t)p * L.total;
+    uint16_t *dst = images + (size_t)q * L.total;
     for (int i = lane * 2; i < L.total; i += WAVE * 2)
         *reinterpret_cast<uint32_t *>(dst + i) =
             *reinterpret_cast<const uint32_t *>(img + i);
 
     for (int o = 32; o > 0; o >>= 1) covered += __shfl_down(covered, o, WAVE);
     if (lane == 0) {
-        counts[p] = 0;
-        counts[n_paths + p] = n_empty;
-        counts[2 * n_paths + p] = filter ? hist_total - covered : 0u;
+        counts[q] = 0;
+        counts[n_paths + q] = n_empty;
+        counts[2 * n_paths + q] = filter ? hist_total - covered : 0u;
     }
+}
+
+// --------------------------------------------------------------------------
+// Longest paths first.  The scan kernel's workgroups are dispatched in index
+// order and a tile's cost grows with the length of its paths, so tiles are
+// formed from the paths in order of decreasing length (longest-processing-time
+// first: the expensive tiles never end up in the tail) and paths of similar
+// length share a tile (an item is in range for all of them or for none).
+// A counting sort on the device; the order among equal lengths is whatever the
+// atomics made it and is not observable (counters are written back by slot).
+// --------------------------------------------------------------------------
+constexpr int LEN_BINS = 1024;
+
+__device__ __forceinline__ int length_bin(const int32_t *path_off, int p)
+{
+    const long long n = (long long)path_off[p + 1] - path_off[p];
+    return GFAL_MAX_STEPS - (int)max(0ll, min(n, (long long)GFAL_MAX_STEPS));
+}
+
+__global__ void k_len_hist(const int32_t *__restrict__ path_off, int n_paths,
+                           uint32_t *__restrict__ bins)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n_paths) atomicAdd(&bins[length_bin(path_off, p)], 1u);
+}
+
+__global__ __launch_bounds__(LEN_BINS) void k_len_offsets(uint32_t *__restrict__ bins)
+{
+    // bins[0..1023] counts -> bins[1024..2047] exclusive offsets, bins[2048..] cursors
+    __shared__ uint32_t part[LEN_BINS];
+    const int tid = threadIdx.x;
+    const uint32_t mine = bins[tid];
+    part[tid] = mine;
+    __syncthreads();
+    for (int o = 1; o < LEN_BINS; o <<= 1) {
+        uint32_t v = tid >= o ? part[tid - o] : 0u;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    bins[LEN_BINS + tid] = part[tid] - mine;
+    bins[2 * LEN_BINS + tid] = 0;
+}
+
+__global__ void k_len_scatter(const int32_t *__restrict__ path_off, int n_paths,
+                              uint32_t *__restrict__ bins, int32_t *__restrict__ order)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_paths) return;
+    const int b = length_bin(path_off, p);
+    order[bins[LEN_BINS + b] + atomicAdd(&bins[2 * LEN_BINS + b], 1u)] = p;
+}
+
+// counters by slot -> counters by caller's path index
+__global__ void k_unpermute(const uint32_t *__restrict__ by_slot,
+                            const int32_t *__restrict__ order, int n_paths,
+                            uint32_t *__restrict__ out)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_paths) return;
+    const int p = order[q];
+    out[p] = by_slot[q];
+    out[n_paths + p] = by_slot[n_paths + q];
+    out[2 * n_paths + p] = by_slot[2 * n_paths + q];
 }
 
 // --------------------------------------------------------------------------
@@ -1156,6 +1222,10 @@ struct gfal_scorer {
     unsigned long long *d_worklist = nullptr;   // as pushed by k_scan
     unsigned long long *d_worklist_sorted = nullptr;
     uint32_t wl_capacity = 0;
+    uint32_t *d_len_bins = nullptr;    // [3 * LEN_BINS] path-length counting sort
+    int32_t *d_order = nullptr;        // [n_paths] slot -> caller's path index
+    uint32_t *d_counts_slot = nullptr; // [3 * n_paths] counters by slot
+    size_t order_cap = 0, counts_slot_cap = 0;
     uint32_t *d_wl_bins = nullptr;     // [3][N_CLASSES * n_paths]: hist | offsets | cursor
     size_t wl_bins_cap = 0;
     uint32_t *d_rows = nullptr;        // DP row scratch
@@ -1209,7 +1279,8 @@ void free_scorer(gfal_scorer *s)
 {
     if (!s) return;
     (void)hipSetDevice(s->device);
-    void *bufs[] = {s->d_item_pairs, s->d_item_pbase,
+    void *bufs[] = {s->d_item_pairs, s->d_item_pbase, s->d_len_bins, s->d_order,
+                    s->d_counts_slot,
                     s->d_node_local, s->d_node_hist, s->d_item_steps, s->d_item_base,
                     s->d_item_len,   s->d_slot_orig, s->d_status,     s->d_worklist,
                     s->d_worklist_sorted, s->d_wl_bins,
@@ -1451,6 +1522,8 @@ int gfal_scorer_create_ex(const int32_t *aln_off, const int32_t *aln_steps,
     if ((rc = dev_upload(&s->d_item_pairs, item_pairs))) return fail(rc);
     if ((rc = dev_upload(&s->d_item_pbase, item_pbase))) return fail(rc);
     if ((rc = dev_upload(&s->d_slot_orig, slot_orig))) return fail(rc);
+    CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_len_bins),
+                         3 * LEN_BINS * sizeof(uint32_t)));
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_status), 4 * sizeof(uint32_t)));
     CREATE_TRY(hipMemset(s->d_status, 0, 4 * sizeof(uint32_t)));
     // worklist: at least one entry per alignment, so a single path always fits
@@ -1512,10 +1585,13 @@ int gfal_scorer_score_device(gfal_scorer *s, const int32_t *d_path_off,
             if (rc) return rc;
         }
         size_t bins = (size_t)3 * N_CLASSES * n_paths + 8;
-        if (bins > s->wl_bins_cap) {
+        if (bins > s->wl_bins_cap || (size_t)n_paths > s->order_cap) {
             if (s->have_last) HIP_TRY(hipStreamSynchronize(s->last_stream));
             int rc = dev_reserve(&s->d_wl_bins, &s->wl_bins_cap, bins);
             if (rc) return rc;
+            if ((rc = dev_reserve(&s->d_order, &s->order_cap, (size_t)n_paths))) return rc;
+            if ((rc = dev_reserve(&s->d_counts_slot, &s->counts_slot_cap, (size_t)3 * n_paths)))
+                return rc;
         }
     }
     const int n_bins = N_CLASSES * n_paths;
@@ -1530,11 +1606,21 @@ int gfal_scorer_score_device(gfal_scorer *s, const int32_t *d_path_off,
 
     const size_t prep_lds = img_bytes + (size_t)L.nm * sizeof(uint16_t) +
                             (size_t)L.v2 * sizeof(uint32_t);
+    // longest paths first (see k_len_*): everything below works on slots
+    const unsigned p_blocks = (unsigned)((n_paths + 255) / 256);
+    uint32_t *const d_user_counts = d_counts;
+    d_counts = s->d_counts_slot;
+    HIP_TRY(hipMemsetAsync(s->d_len_bins, 0, LEN_BINS * sizeof(uint32_t), st));
+    hipLaunchKernelGGL(k_len_hist, dim3(p_blocks), dim3(256), 0, st, d_path_off, (int)n_paths,
+                       s->d_len_bins);
+    hipLaunchKernelGGL(k_len_offsets, dim3(1), dim3(LEN_BINS), 0, st, s->d_len_bins);
+    hipLaunchKernelGGL(k_len_scatter, dim3(p_blocks), dim3(256), 0, st, d_path_off,
+                       (int)n_paths, s->d_len_bins, s->d_order);
     hipLaunchKernelGGL(k_prep, dim3((unsigned)n_paths), dim3(WAVE), prep_lds, st,
                        d_path_off, d_path_steps, (int)n_paths, total_steps,
                        (int)max_path_len, s->d_node_local, (int)s->n_nodes,
                        s->d_node_hist, (uint32_t)s->n_steps, s->n_empty, filter, L,
-                       s->d_images, d_counts, s->d_status);
+                       s->d_order, s->d_images, d_counts, s->d_status);
     HIP_TRY(hipGetLastError());
     if (s->profiling) HIP_TRY(hipEventRecord(ev[1], st));
 
@@ -1614,6 +1700,9 @@ int gfal_scorer_score_device(gfal_scorer *s, const int32_t *d_path_off,
     } else if (s->profiling) {
         HIP_TRY(hipEventRecord(ev[2], st));
     }
+    hipLaunchKernelGGL(k_unpermute, dim3(p_blocks), dim3(256), 0, st, d_counts, s->d_order,
+                       (int)n_paths, d_user_counts);
+    HIP_TRY(hipGetLastError());
     if (s->profiling) {
         HIP_TRY(hipEventRecord(ev[3], st));
         ++s->ev_calls;
@@ -1748,7 +1837,7 @@ int gfal_scorer_pair_scores(gfal_scorer *s, const int32_t *path_steps, int32_t n
     hipLaunchKernelGGL(k_prep, dim3(1), dim3(WAVE), prep_lds, s->stream, s->d_path_off,
                        s->d_path_steps, 1, (int64_t)n, (int)n, s->d_node_local,
                        (int)s->n_nodes, s->d_node_hist, (uint32_t)s->n_steps,
-                       s->n_empty, 0, L, s->d_images, s->d_counts, s->d_status);
+                       s->n_empty, 0, L, nullptr, s->d_images, s->d_counts, s->d_status);
     HIP_TRY(hipGetLastError());
 
     int32_t *d_fw = nullptr, *d_rc = nullptr;
