@@ -1237,6 +1237,10 @@ struct gfal_scorer {
     uint32_t *d_counts = nullptr;
     size_t path_off_cap = 0, path_steps_cap = 0, counts_cap = 0;
     hipStream_t stream = nullptr;      // owned, for the blocking API
+    // the DP kernels of the different length classes run side by side: each is
+    // bound by the latency of its longest single fill, not by throughput
+    hipStream_t dp_stream[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t dp_fork = nullptr, dp_join[3] = {nullptr, nullptr, nullptr};
 
     // last call
     hipStream_t last_stream = nullptr;
@@ -1292,6 +1296,11 @@ void free_scorer(gfal_scorer *s)
         for (hipEvent_t e : set)
             if (e) (void)hipEventDestroy(e);
     if (s->stream) (void)hipStreamDestroy(s->stream);
+    for (hipStream_t x : s->dp_stream)
+        if (x) (void)hipStreamDestroy(x);
+    if (s->dp_fork) (void)hipEventDestroy(s->dp_fork);
+    for (hipEvent_t e : s->dp_join)
+        if (e) (void)hipEventDestroy(e);
     delete s;
 }
 
@@ -1508,6 +1517,11 @@ int gfal_scorer_create_ex(const int32_t *aln_off, const int32_t *aln_steps,
     } while (0)
     CREATE_TRY(hipSetDevice(device));
     CREATE_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    CREATE_TRY(hipEventCreateWithFlags(&s->dp_fork, hipEventDisableTiming));
+    for (int i = 0; i < 3; ++i) {
+        CREATE_TRY(hipStreamCreateWithFlags(&s->dp_stream[i], hipStreamNonBlocking));
+        CREATE_TRY(hipEventCreateWithFlags(&s->dp_join[i], hipEventDisableTiming));
+    }
     // both kernels may ask for more than the default 64 KiB of dynamic LDS
     CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan),
                                    hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1681,21 +1695,38 @@ int gfal_scorer_score_device(gfal_scorer *s, const int32_t *d_path_off,
         d.wl_capacity = s->wl_capacity;
         d.row_scratch = s->d_rows;
         d.counts = d_counts;
+        // fork: classes 8 / 16 / 32+ on side streams, class 4 on the caller's
+        HIP_TRY(hipEventRecord(s->dp_fork, st));
+        int forked = 0;
+        auto side = [&](int i) -> hipStream_t {
+            (void)hipStreamWaitEvent(s->dp_stream[i], s->dp_fork, 0);
+            forked |= 1 << i;
+            return s->dp_stream[i];
+        };
         hipLaunchKernelGGL((k_dp_regs<4, 0>), dim3(DP_REG_BLOCKS), dim3(DP_THREADS), 0, st, d);
         if (s->max_aln_len > 4)
-            hipLaunchKernelGGL((k_dp_regs<8, 1>), dim3(DP_REG_BLOCKS), dim3(DP_THREADS), 0, st, d);
+            hipLaunchKernelGGL((k_dp_regs<8, 1>), dim3(DP_REG_BLOCKS), dim3(DP_THREADS), 0,
+                               side(0), d);
         if (s->max_aln_len > 8)
-            hipLaunchKernelGGL((k_dp_regs<16, 2>), dim3(DP_REG_BLOCKS), dim3(DP_THREADS), 0, st, d);
-        if (s->max_aln_len > 16)
-            hipLaunchKernelGGL((k_dp_regs<32, 3>), dim3(DP_REG_BLOCKS), dim3(DP_THREADS), 0, st, d);
-        if (s->max_aln_len > 32) {
-            if (dp_rows_fit_lds(s->max_aln_len))
-                hipLaunchKernelGGL(k_dp_long<true>, dim3(DP_BLOCKS), dim3(DP_THREADS),
-                                   dp_lds_bytes(s->max_aln_len), st, d);
-            else
-                hipLaunchKernelGGL(k_dp_long<false>, dim3(DP_BLOCKS), dim3(DP_THREADS), 0,
-                                   st, d);
+            hipLaunchKernelGGL((k_dp_regs<16, 2>), dim3(DP_REG_BLOCKS), dim3(DP_THREADS), 0,
+                               side(1), d);
+        if (s->max_aln_len > 16) {
+            hipStream_t s2 = side(2);
+            hipLaunchKernelGGL((k_dp_regs<32, 3>), dim3(DP_REG_BLOCKS), dim3(DP_THREADS), 0, s2, d);
+            if (s->max_aln_len > 32) {
+                if (dp_rows_fit_lds(s->max_aln_len))
+                    hipLaunchKernelGGL(k_dp_long<true>, dim3(DP_BLOCKS), dim3(DP_THREADS),
+                                       dp_lds_bytes(s->max_aln_len), s2, d);
+                else
+                    hipLaunchKernelGGL(k_dp_long<false>, dim3(DP_BLOCKS), dim3(DP_THREADS), 0,
+                                       s2, d);
+            }
         }
+        for (int i = 0; i < 3; ++i)        // join
+            if (forked & (1 << i)) {
+                HIP_TRY(hipEventRecord(s->dp_join[i], s->dp_stream[i]));
+                HIP_TRY(hipStreamWaitEvent(st, s->dp_join[i], 0));
+            }
         HIP_TRY(hipGetLastError());
     } else if (s->profiling) {
         HIP_TRY(hipEventRecord(ev[2], st));
