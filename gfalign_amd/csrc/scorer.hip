@@ -1391,6 +1391,7 @@ int gfal_scorer_create_ex(const int32_t *aln_off, const int32_t *aln_steps,
     int max_len = 0;
     uint32_t n_empty = 0;
     bool any_outside = false;
+    std::vector<uint32_t> visit_order;
     for (int64_t k = 0; k < n_aln; ++k) {
         int64_t m = (int64_t)aln_off[k + 1] - aln_off[k];
         if (m < 0 || aln_off[k + 1] > S) return GFAL_E_ARG;
@@ -1411,9 +1412,92 @@ int gfal_scorer_create_ex(const int32_t *aln_off, const int32_t *aln_steps,
         if (node_local[s >> 1] == -1) node_local[s >> 1] = 0;
         else if (node_local[s >> 1] == -2) any_outside = true;
     }
+    // Local ids follow a walk over the graph the alignments themselves trace
+    // out (consecutive steps = an edge, weight = how often): depth-first along
+    // the heaviest unvisited edge.  Nodes that are neighbours on the tangle get
+    // neighbouring ids, so the content-sorted items hold alignments from one
+    // region of the tangle: the lanes of a wave then agree on which candidate
+    // paths they touch.  Any numbering gives the same counters; this one is
+    // 7-15 % faster than the caller's order on the synthetic tangles.
     int n_local = 0;
-    for (int32_t v = 0; v < n_nodes; ++v)
-        if (node_local[v] == 0) node_local[v] = n_local++;
+    {
+        std::vector<uint64_t> edges;
+        const int64_t max_edges = (int64_t)4 << 20;
+        const int64_t stride = std::max<int64_t>(1, S / max_edges);
+        for (int64_t k = 0; k < n_aln; k += stride)
+            for (int64_t t = aln_off[k]; t + 1 < aln_off[k + 1]; ++t) {
+                const uint32_t u = (uint32_t)(aln_steps[t] >> 1), w = (uint32_t)(aln_steps[t + 1] >> 1);
+                if (u != w && node_local[u] == 0 && node_local[w] == 0)
+                    edges.push_back(((uint64_t)std::min(u, w) << 32) | std::max(u, w));
+            }
+        std::sort(edges.begin(), edges.end());
+        struct Nb { uint32_t to, weight; };
+        std::vector<uint32_t> deg((size_t)n_nodes + 1, 0);
+        std::vector<std::pair<uint64_t, uint32_t>> uniq;     // edge, multiplicity
+        for (size_t i = 0; i < edges.size();) {
+            size_t j = i;
+            while (j < edges.size() && edges[j] == edges[i]) ++j;
+            uniq.emplace_back(edges[i], (uint32_t)(j - i));
+            ++deg[(size_t)(edges[i] >> 32)];
+            ++deg[(size_t)(edges[i] & 0xFFFFFFFFu)];
+            i = j;
+        }
+        std::vector<size_t> at((size_t)n_nodes + 1, 0);
+        for (int32_t v = 0; v < n_nodes; ++v) at[(size_t)v + 1] = at[(size_t)v] + deg[(size_t)v];
+        std::vector<Nb> nb(at[(size_t)n_nodes]);
+        std::vector<size_t> fill(at.begin(), at.end() - 1);
+        for (auto &e : uniq) {
+            const uint32_t u = (uint32_t)(e.first >> 32), w = (uint32_t)(e.first & 0xFFFFFFFFu);
+            nb[fill[u]++] = Nb{w, e.second};
+            nb[fill[w]++] = Nb{u, e.second};
+        }
+        for (int32_t v = 0; v < n_nodes; ++v)
+            std::sort(nb.begin() + (ptrdiff_t)at[(size_t)v], nb.begin() + (ptrdiff_t)at[(size_t)v + 1],
+                      [](const Nb &x, const Nb &y) {
+                          return x.weight != y.weight ? x.weight > y.weight : x.to < y.to;
+                      });
+        std::vector<size_t> cursor(at.begin(), at.end() - 1);   // next neighbour to try
+        auto next_unvisited = [&](uint32_t v) -> int64_t {
+            while (cursor[v] < at[(size_t)v + 1]) {
+                const uint32_t w = nb[cursor[v]].to;
+                if (node_local[w] == 0) return w;
+                ++cursor[v];
+            }
+            return -1;
+        };
+        std::vector<uint32_t> stack;
+        // first start: an end of the walk if there is one (fewest neighbours)
+        int32_t first_start = -1;
+        for (int32_t v = 0; v < n_nodes; ++v)
+            if (node_local[v] == 0 && deg[(size_t)v] > 0 &&
+                (first_start < 0 || deg[(size_t)v] < deg[(size_t)first_start]))
+                first_start = v;
+        auto walk_from = [&](uint32_t start) {
+            uint32_t cur = start;
+            while (true) {
+                node_local[cur] = -3;            // visited, id assigned below
+                visit_order.push_back(cur);
+                int64_t nx = next_unvisited(cur);
+                if (nx >= 0) {
+                    stack.push_back(cur);
+                    cur = (uint32_t)nx;
+                    continue;
+                }
+                nx = -1;
+                while (!stack.empty()) {
+                    nx = next_unvisited(stack.back());
+                    if (nx >= 0) break;
+                    stack.pop_back();
+                }
+                if (nx < 0) break;
+                cur = (uint32_t)nx;
+            }
+        };
+        if (first_start >= 0) walk_from((uint32_t)first_start);
+        for (int32_t v = 0; v < n_nodes; ++v)
+            if (node_local[v] == 0) walk_from((uint32_t)v);
+        for (uint32_t v : visit_order) node_local[v] = n_local++;
+    }
     // every node outside the universe shares one local id: no path can carry
     // it, so such steps only ever fail the filter / a comparison, and their
     // histogram bin keeps `unaligned` exact
