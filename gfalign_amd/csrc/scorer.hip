@@ -1138,110 +1138,6 @@ __global__ __launch_bounds__(DP_THREADS) void k_dp_regs(DpArgs a)
     }
 }
 
-// Length classes 0..2 (up to 16 steps): one pair per MC lanes, one column of
-// the table per lane, rows streaming through as a wavefront ("systolic").
-// At step s lane c fills cell (i = s - c, j = c + 1); what it needs from
-// column j-1 -- the cell to the left (row i) and the diagonal one (row i-1) --
-// are its left neighbour's results of steps s-1 and s-2, fetched with DPP
-// row_shr:1.  One pair's fill takes n + MC steps of ~20 instructions instead
-// of n * MC cells of 12: the kernel is bound by the longest single fill, so
-// this is what matters (a 900-step path: 0.4 ms thread-per-pair, 0.03 ms here).
-template <int MC>
-__device__ __forceinline__ int dpp_from_left(int v)
-{
-    // row_shr:1 inside 16-lane rows; lanes without a source keep `v`
-    return __builtin_amdgcn_update_dpp(v, v, 0x111, 0xF, 0xF, false);
-}
-
-template <int MC, int CLS>
-__global__ __launch_bounds__(DP_THREADS) void k_dp_sys(DpArgs a)
-{
-    constexpr int G = WAVE / MC;                     // pairs per wave
-    __shared__ uint16_t apath[G][GFAL_MAX_STEPS + 8];   // the groups' path steps
-    if (*a.wl_count > a.wl_capacity) return;         // overflow: see k_wl_scatter
-    const uint32_t total = *a.wl_count;
-    uint32_t lo, hi;
-    class_range(a.class_lo, CLS, total, lo, hi);
-    const int lane = threadIdx.x;
-    const int c = lane % MC, g = lane / MC;
-    const int j = c + 1;
-    for (uint32_t w0 = lo + blockIdx.x * G; w0 < hi; w0 += gridDim.x * G) {
-        const uint32_t w = w0 + g;
-        const bool live = w < hi;
-        const DpEntry e = load_entry(a, w, live);
-        // stage the path of every group (neighbouring groups usually share it)
-        __syncthreads();
-        int my_row = g;
-        {
-            uint32_t prev_p = 0xFFFFFFFFu;
-            int prev_row = 0;
-            for (int gg = 0; gg < G; ++gg) {
-                const uint32_t p_gg = (uint32_t)__builtin_amdgcn_readlane((int)e.p, gg * MC);
-                const int n_gg = __builtin_amdgcn_readlane(e.n, gg * MC);
-                int row = gg;
-                if (gg > 0 && p_gg == prev_p) {
-                    row = prev_row;
-                } else if (n_gg > 0) {
-                    const uint16_t *src = a.images + (size_t)p_gg * a.L.total + a.L.step_at();
-                    for (int i = lane; i < n_gg; i += WAVE) apath[gg][i] = src[i];
-                }
-                if (g == gg) my_row = row;
-                prev_p = p_gg;
-                prev_row = row;
-            }
-        }
-        __syncthreads();
-        const uint16_t *arow = apath[my_row];
-
-        bool good = false;
-        for (int pass = 0; pass < 2; ++pass) {
-            // pass 0: the forward orientation if flagged, else the reverse one;
-            // pass 1: the reverse one for pairs with both flags
-            const bool run = live && (pass == 0 || (e.has_fw && e.has_rc));
-            if (!WAVE_ANY(run)) break;
-            const bool flip = pass == 1 || !e.has_fw;
-            const int n = run ? e.n : 0, m = e.m;
-            uint32_t b = STEP_INVALID;
-            if (run && c < m)
-                b = flip ? ((uint32_t)e.bp[(m - 1 - c) * WAVE] ^ 1u) : (uint32_t)e.bp[c * WAVE];
-            // row 0 of my column (src/alignments.cpp:500: initialised up to column n)
-            int l_dp = (j <= n) ? -j : 0, l_x = l_dp;     // my latest cell
-            int p_dp = l_dp, p_x = l_dp;                  // the one before it
-            uint32_t a_cur = 0;
-            int n_max = n;                                // longest path in the wave
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) n_max = max(n_max, __shfl_xor(n_max, o, WAVE));
-            for (int s = 1; s < n_max + MC; ++s) {
-                // path step of row i = s - c: enters at lane 0, moves right
-                const uint32_t a_left = (uint32_t)dpp_from_left<MC>((int)a_cur);
-                a_cur = (c == 0) ? (s <= n ? (uint32_t)arow[s - 1] : 0u) : a_left;
-                int nl_dp = dpp_from_left<MC>(l_dp), nl_x = dpp_from_left<MC>(l_x);
-                int np_dp = dpp_from_left<MC>(p_dp), np_x = dpp_from_left<MC>(p_x);
-                if (c == 0) {                              // column 0 is all zeros
-                    nl_dp = nl_x = np_dp = np_x = 0;
-                }
-                const int i = s - c;
-                const int d = np_dp + ((a_cur == b) ? 0 : -1);
-                const int u = l_dp + ((j < m) ? -1 : 0);   // :504 free in the last column
-                const int lft = nl_dp - 1;
-                const int v = max(d, max(u, lft));
-                const int xx = (v == d) ? np_x : ((l_dp >= nl_dp) ? l_x : nl_x);
-                if (i >= 1 && i <= n) {
-                    p_dp = l_dp;
-                    p_x = l_x;
-                    l_dp = v;
-                    l_x = xx;
-                }
-            }
-            // lane m-1 of the group holds cell (n, m)
-            good |= run && c == m - 1 && l_dp - l_x == 0;
-        }
-        const lanemask gm = WAVE_MASK(good);
-        const lanemask mine = (gm >> (g * MC)) & ((MC == 64) ? ~0ull : ((1ull << MC) - 1ull));
-        if (live && c == 0) atomicAdd(&a.counts[(mine != 0 ? a.n_paths : 0) + e.p], 1u);
-    }
-}
-
 // Last length class (more than 32 steps): rows in LDS or HBM.
 template <bool ROWS_IN_LDS>
 __global__ __launch_bounds__(DP_THREADS) void k_dp_long(DpArgs a)
@@ -1893,12 +1789,12 @@ int gfal_scorer_score_device(gfal_scorer *s, const int32_t *d_path_off,
             forked |= 1 << i;
             return s->dp_stream[i];
         };
-        hipLaunchKernelGGL((k_dp_sys<4, 0>), dim3(DP_REG_BLOCKS), dim3(DP_THREADS), 0, st, d);
+        hipLaunchKernelGGL((k_dp_regs<4, 0>), dim3(DP_REG_BLOCKS), dim3(DP_THREADS), 0, st, d);
         if (s->max_aln_len > 4)
-            hipLaunchKernelGGL((k_dp_sys<8, 1>), dim3(DP_REG_BLOCKS), dim3(DP_THREADS), 0,
+            hipLaunchKernelGGL((k_dp_regs<8, 1>), dim3(DP_REG_BLOCKS), dim3(DP_THREADS), 0,
                                side(0), d);
         if (s->max_aln_len > 8)
-            hipLaunchKernelGGL((k_dp_sys<16, 2>), dim3(DP_REG_BLOCKS), dim3(DP_THREADS), 0,
+            hipLaunchKernelGGL((k_dp_regs<16, 2>), dim3(DP_REG_BLOCKS), dim3(DP_THREADS), 0,
                                side(1), d);
         if (s->max_aln_len > 16) {
             hipStream_t s2 = side(2);
