@@ -22,14 +22,65 @@ def shard_bounds(aln_off, world_size):
     return np.maximum.accumulate(bounds)
 
 
-def take_shard(aln_off, aln_steps, rank, world_size):
-    """CSR arrays of this rank's alignments (offsets re-based to 0)."""
-    b = shard_bounds(aln_off, world_size)
-    lo, hi = int(b[rank]), int(b[rank + 1])
+def content_owner(aln_off, aln_steps, world_size):
+    """Rank that owns each alignment under the "content" policy: a hash of the
+    alignment's steps, so all copies of one alignment live on one rank.
+
+    The scan kernel works on 64 content-sorted alignments at a time and is
+    fastest when they are (near-)identical; cutting the input into contiguous
+    ranges spreads the copies of every alignment over all ranks (8x fewer
+    copies per rank at 8 GPUs: +35 % scan work per alignment, measured), a
+    content hash keeps them together and still balances the ranks.
+    """
+    aln_off = np.asarray(aln_off, dtype=np.int64)
+    steps = np.asarray(aln_steps).astype(np.uint64)
+    m = np.diff(aln_off)
+    pos = np.arange(len(steps), dtype=np.uint64) - np.repeat(aln_off[:-1], m).astype(np.uint64)
+    with np.errstate(over="ignore"):
+        mixed = (steps + np.uint64(1)) * (np.uint64(0x9E3779B97F4A7C15) + pos * np.uint64(0xBF58476D1CE4E5B9))
+        mixed ^= mixed >> np.uint64(29)
+        h = np.zeros(len(m), np.uint64)
+        nz = m > 0
+        h[nz] = np.add.reduceat(mixed, aln_off[:-1][nz])
+        h = (h ^ (h >> np.uint64(31))) * np.uint64(0x94D049BB133111EB)
+        h ^= h >> np.uint64(32)
+    # groups of identical alignments, heaviest first, dealt to the ranks in
+    # serpentine order: step counts end up within a fraction of a percent
+    _, inverse, = np.unique(h, return_inverse=True)[:2]
+    weight = np.bincount(inverse, weights=m.astype(np.float64))
+    by_weight = np.argsort(-weight, kind="stable")
+    turn = np.arange(len(by_weight)) % (2 * world_size)
+    rank_of_turn = np.where(turn < world_size, turn, 2 * world_size - 1 - turn)
+    group_owner = np.empty(len(by_weight), np.int64)
+    group_owner[by_weight] = rank_of_turn
+    return group_owner[inverse]
+
+
+def take_shard(aln_off, aln_steps, rank, world_size, policy="content"):
+    """CSR arrays of this rank's alignments (offsets re-based to 0).
+
+    policy "content" (default): alignments are dealt to ranks by a hash of their
+    steps (see content_owner); "range": contiguous ranges balanced by step
+    count (shard_bounds).  Any partition gives the same summed counters.
+    """
     aln_off = np.asarray(aln_off)
-    off = (aln_off[lo:hi + 1] - aln_off[lo]).astype(np.int32)
-    steps = np.asarray(aln_steps)[aln_off[lo]:aln_off[hi]].astype(np.int32)
-    return off, steps
+    aln_steps = np.asarray(aln_steps)
+    if world_size == 1:
+        return aln_off.astype(np.int32), aln_steps.astype(np.int32)
+    if policy == "range":
+        b = shard_bounds(aln_off, world_size)
+        lo, hi = int(b[rank]), int(b[rank + 1])
+        off = (aln_off[lo:hi + 1] - aln_off[lo]).astype(np.int32)
+        steps = aln_steps[aln_off[lo]:aln_off[hi]].astype(np.int32)
+        return off, steps
+    if policy != "content":
+        raise ValueError("unknown sharding policy %r" % policy)
+    mine = np.flatnonzero(content_owner(aln_off, aln_steps, world_size) == rank)
+    m = (aln_off[mine + 1] - aln_off[mine]).astype(np.int64)
+    off = np.zeros(len(mine) + 1, np.int64)
+    np.cumsum(m, out=off[1:])
+    idx = np.arange(off[-1], dtype=np.int64) - np.repeat(off[:-1], m) + np.repeat(aln_off[mine].astype(np.int64), m)
+    return off.astype(np.int32), aln_steps[idx].astype(np.int32)
 
 
 def all_reduce_counts(counts, group=None):

@@ -23,7 +23,7 @@ if os.environ.get("RELABEL"):
     first[rest] = seen + np.arange(len(rest))
     remap = lambda a: ((first[a >> 1] << 1) | (a & 1)).astype(np.int32)
     t.aln_steps = remap(t.aln_steps); t.path_steps = remap(t.path_steps)
-off, st = shard.take_shard(t.aln_off, t.aln_steps, 0, world)
+off, st = shard.take_shard(t.aln_off, t.aln_steps, 0, world, os.environ.get('POLICY', 'content'))
 dev = torch.device("cuda", 0)
 sc = Scorer(off, st, t.V)
 P = t.P

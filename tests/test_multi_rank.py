@@ -57,19 +57,33 @@ def test_shard_bounds_cover_everything_once():
         sizes = [int(t.aln_off[b[r + 1]] - t.aln_off[b[r]]) for r in range(world)]
         assert sum(sizes) == t.S
         assert max(sizes) - min(sizes) <= 64          # balanced by step count
-        total = 0
-        for r in range(world):
-            off, st = shard.take_shard(t.aln_off, t.aln_steps, r, world)
-            assert off[0] == 0 and off[-1] == len(st)
-            total += len(off) - 1
-        assert total == t.N
+        for policy in ("range", "content"):
+            total, steps = 0, 0
+            for r in range(world):
+                off, st = shard.take_shard(t.aln_off, t.aln_steps, r, world, policy)
+                assert off[0] == 0 and off[-1] == len(st)
+                total += len(off) - 1
+                steps += len(st)
+                if world > 1:
+                    assert abs(len(st) - t.S / world) < 0.05 * t.S / world   # balanced
+            assert total == t.N and steps == t.S
+
+
+def test_content_policy_keeps_copies_together():
+    t = synth.make("config2")
+    owner = shard.content_owner(t.aln_off, t.aln_steps, 8)
+    seen = {}
+    for k in range(0, t.N, 7):
+        key = t.aln_steps[t.aln_off[k]:t.aln_off[k + 1]].tobytes()
+        assert seen.setdefault(key, owner[k]) == owner[k]
 
 
 def test_more_ranks_than_alignments():
     off = np.array([0, 2, 5], np.int32)
     st = np.arange(5, dtype=np.int32)
-    seen = 0
-    for r in range(4):
-        o, s = shard.take_shard(off, st, r, 4)
-        seen += len(o) - 1
-    assert seen == 2
+    for policy in ("range", "content"):
+        seen = 0
+        for r in range(4):
+            o, s = shard.take_shard(off, st, r, 4, policy)
+            seen += len(o) - 1
+        assert seen == 2
