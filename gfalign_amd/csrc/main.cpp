@@ -422,6 +422,7 @@ int main(int argc, char **argv)
         printf("\n");
     }
 
+    const double t_start = gfal::now_s();
     Graph g;
     std::string err;
     if (!o.gfa.empty() && !read_gfa(o.gfa, g, err)) {
@@ -441,6 +442,7 @@ int main(int argc, char **argv)
     switch (o.mode) {
     case 1: return run_eval_gfa(o, recs, totals);
     case 3: {
+        const double t_read = gfal::now_s();
         PackedAlignments packed;
         for (auto &r : recs) packed.add(r, g);
         if (!g.ids.count(o.source) || !g.ids.count(o.destination)) {
@@ -460,6 +462,7 @@ int main(int argc, char **argv)
                 if (it != g.ids.end()) universe.push_back((int32_t)it->second);
             }
         }
+        const double t_pack = gfal::now_s();
         PathScorer scorer;
         const bool share = getenv("GFALIGN_SHARE_DEVICE") != nullptr;
         if (!scorer.open(packed, (int32_t)g.headers.size(), o.device, universe, o.n_devices,
@@ -473,8 +476,15 @@ int main(int argc, char **argv)
         so.min_nodes = o.min_nodes;
         so.return_all_paths = o.return_all_paths != 0;
         if (const char *k = getenv("GFALIGN_SPECULATE")) so.speculate = (size_t)std::max(1, atoi(k));
+        const double t_open = gfal::now_s();
         Search search(g, scorer, so, std::cout);
         int rc = search.run();
+        if (verbose_flag)
+            fprintf(stderr,
+                    "time: read %.3f s, pack %.3f s, scorer %.3f s, search %.3f s (candidates %.3f s, "
+                    "scoring %.3f s)\n",
+                    t_read - t_start, t_pack - t_read, t_open - t_pack, gfal::now_s() - t_open,
+                    search.collect_seconds(), search.score_seconds());
         if (verbose_flag)
             fprintf(stderr, "scored %llu candidate paths in %llu batches\n",
                     (unsigned long long)search.scored_paths(),

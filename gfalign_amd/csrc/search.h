@@ -10,6 +10,7 @@
 #define GFALIGN_SEARCH_H
 
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -26,6 +27,12 @@
 #include "graph_io.h"
 
 namespace gfal {
+
+inline double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch())
+        .count();
+}
 
 // reference include/alignments.h:11-21
 struct Step {
@@ -86,11 +93,11 @@ struct NodeTable {
         node_count += count;
     }
     // nodetable.h:56-67
-    bool hamiltonian(const std::vector<Step> &path) const
+    bool hamiltonian(const std::vector<int32_t> &packed_path) const
     {
-        if (path.size() + 2 != node_count) return false;
+        if (packed_path.size() + 2 != node_count) return false;
         std::unordered_map<uint32_t, uint32_t> seen;
-        for (auto &s : path) ++seen[(uint32_t)s.id];
+        for (int32_t s : packed_path) ++seen[(uint32_t)(s & ~GFAL_STEP_OTHER) >> 1];
         for (auto &r : records) {
             auto it = seen.find(r.uid);
             if (it == seen.end() || it->second != r.count) return false;
@@ -104,6 +111,18 @@ inline std::string path_string(const std::vector<Step> &p, const Graph &g)
     std::string s;   // include/alignments.h:72-80
     for (size_t i = 0; i < p.size(); ++i) {
         s += g.headers[(size_t)p[i].id] + p[i].orientation;
+        if (i + 1 < p.size()) s += ',';
+    }
+    return s;
+}
+
+// the same from packed steps: "utig4-1+,utig4-2-"
+inline std::string path_string(const std::vector<int32_t> &p, const Graph &g)
+{
+    std::string s;
+    for (size_t i = 0; i < p.size(); ++i) {
+        s += g.headers[(size_t)((uint32_t)(p[i] & ~GFAL_STEP_OTHER) >> 1)];
+        s += (p[i] & GFAL_STEP_OTHER) ? '0' : (p[i] & 1) ? '-' : '+';
         if (i + 1 < p.size()) s += ',';
     }
     return s;
@@ -320,10 +339,14 @@ public:
                 record_of_[table.records[r].uid] = (int)r;
         }
 
+        // extension budget per uid (:142-143): the record's count, 0 = not listed
+        allowance_.assign(g_.headers.size(), 0);
+        for (size_t u = 0; u < record_of_.size(); ++u)
+            if (record_of_[u] >= 0) allowance_[u] = table.records[(size_t)record_of_[u]].count;
+
         auto first = std::make_unique<Node>();
-        first->path.push_back({(int32_t)src_uid, '0'});                     // :130
-        first->budget.resize(table.records.size());
-        for (size_t r = 0; r < table.records.size(); ++r) first->budget[r] = table.records[r].count;
+        first->path.push_back(GFAL_STEP_OTHER | (int32_t)(src_uid << 1));   // :130, orientation '0'
+        first->uniques = 1;
         queue_.emplace(Key{0, seq_++}, std::move(first));                   // :132
 
         uint64_t path_counter = 0;
@@ -365,13 +388,17 @@ public:
 
     uint64_t scored_paths() const { return scored_; }
     uint64_t batches() const { return batches_; }
+    double collect_seconds() const { return t_collect_; }
+    double score_seconds() const { return t_score_; }
 
 private:
     // A candidate path: a queue entry, or a pre-generated extension of one.
+    // The per-path NodeTable copy of the reference (include/alignments.h:26) is not
+    // stored: a record's remaining count is its initial count minus the node's
+    // occurrences in path[1..] (every non-destination extension decrements it once,
+    // :166-167; the source at path[0] was never an extension), see make_kids.
     struct Node {
-        std::vector<Step> path;
-        std::vector<uint32_t> budget;   // per node-table record, as the entry would
-                                        // carry it in the queue (include/alignments.h:26)
+        std::vector<int32_t> path;      // packed steps, as the scorer takes them
         uint32_t uniques = 0, bad = 0, good = 0;
         bool at_destination = false;
         bool kids_made = false, kids_scored = false;
@@ -390,21 +417,28 @@ private:
     void make_kids(Node &e) const
     {
         e.kids_made = true;
-        const Step last = e.path.back();
-        for (const Edge &v : g_.adjacency[(size_t)last.id]) {
-            if (last.orientation != '0' && last.orientation != v.from_orient) continue;   // :137
-            const int rec = record_of_[v.to];
-            if (rec < 0 || e.budget[(size_t)rec] == 0) continue;                          // :142-143
+        const int32_t last = e.path.back();
+        const bool fresh = (last & GFAL_STEP_OTHER) != 0;          // orientation still '0'
+        const uint32_t last_id = (uint32_t)(last & ~GFAL_STEP_OTHER) >> 1;
+        const char last_orient = (last & 1) ? '-' : '+';
+        const size_t n = e.path.size();
+        for (const Edge &v : g_.adjacency[last_id]) {
+            if (!fresh && last_orient != v.from_orient) continue;                         // :137
+            const uint32_t allowed = allowance_[v.to];
+            if (allowed == 0) continue;                                                   // :142-143
+            // times this node was stepped on so far; ids compare with the
+            // orientation bit masked off (path[0] may still carry the '0' flag)
+            uint32_t used = 0;
+            for (size_t i = 1; i < n; ++i) used += ((uint32_t)e.path[i] >> 1) == v.to;
+            if (used >= allowed) continue;
+            const bool seen = used > 0 || ((uint32_t)(e.path[0] & ~GFAL_STEP_OTHER) >> 1) == v.to;
             auto c = std::make_unique<Node>();
+            c->path.reserve(n + 1);
             c->path = e.path;
-            if (c->path.back().orientation == '0') c->path.back().orientation = v.from_orient;
-            c->path.push_back({(int32_t)v.to, v.to_orient});
-            c->uniques = count_uniques(c->path);
+            if (fresh) c->path.back() = (int32_t)(last_id << 1) | (v.from_orient == '-');   // :148-149
+            c->path.push_back((int32_t)(v.to << 1) | (v.to_orient == '-'));
+            c->uniques = e.uniques + (seen ? 0u : 1u);                                    // :153-160
             c->at_destination = v.to == dest_uid_;
-            if (!c->at_destination) {
-                c->budget = e.budget;
-                --c->budget[(size_t)rec];
-            }
             e.kids.push_back(std::move(c));
         }
     }
@@ -413,6 +447,7 @@ private:
     // the best queue entries (front first), breadth-first.
     bool expand_front()
     {
+        const double t0 = now_s();
         std::vector<Node *> level, parents;   // parents: nodes whose kids get scored now
         std::vector<int32_t> off{0}, steps;
         size_t n_paths = 0;
@@ -431,7 +466,7 @@ private:
                     make_kids(*e);
                     parents.push_back(e);
                     for (auto &c : e->kids) {
-                        for (const Step &s : c->path) steps.push_back(pack(s));
+                        steps.insert(steps.end(), c->path.begin(), c->path.end());
                         off.push_back((int32_t)steps.size());
                         ++n_paths;
                     }
@@ -442,7 +477,10 @@ private:
             level.swap(next);
         }
         std::vector<uint32_t> bad, good;
+        const double t1 = now_s();
+        t_collect_ += t1 - t0;
         if (!scorer_.score(off, steps, true, bad, good)) return false;   // :162
+        t_score_ += now_s() - t1;
         size_t k = 0;
         for (Node *e : parents) {
             for (auto &c : e->kids) {
@@ -463,8 +501,10 @@ private:
     std::ostream &out_;
     uint32_t dest_uid_ = 0;
     std::vector<int> record_of_;
+    std::vector<uint32_t> allowance_;
     std::map<Key, std::unique_ptr<Node>> queue_;
     uint64_t seq_ = 0, scored_ = 0, batches_ = 0;
+    double t_collect_ = 0, t_score_ = 0;
 };
 
 }  // namespace gfal

@@ -22,4 +22,4 @@ for steps in (int(x) for x in (sys.argv[2].split(",") if len(sys.argv) > 2 else 
         dt = time.time() - t0
         rows = p.stdout.strip().splitlines()
         print("steps %5d spec %5s: %.2f s  rows %d  last: %s | %s" % (
-            steps, spec, dt, len(rows), rows[-1][:60] if rows else "", p.stderr.strip().splitlines()[-1] if p.stderr.strip() else ""))
+            steps, spec, dt, len(rows), rows[-1][:60] if rows else "", " / ".join(p.stderr.strip().splitlines()[-2:])))
