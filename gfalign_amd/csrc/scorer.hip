@@ -1089,6 +1089,7 @@ struct DpArgs {
     const uint32_t *class_lo;   // [N_CLASSES + 1] ranges of the sorted list
     const uint32_t *wl_count;
     uint32_t wl_capacity;
+    uint32_t sys_limit;         // worklists up to this size take the k_dp_sys kernels
     uint32_t *row_scratch;
     uint32_t *counts;
 };
@@ -1123,6 +1124,7 @@ __global__ __launch_bounds__(DP_THREADS) void k_dp_regs(DpArgs a)
 {
     if (*a.wl_count > a.wl_capacity) return;     // overflow: see k_wl_scatter
     const uint32_t total = *a.wl_count;
+    if (total <= a.sys_limit) return;            // short list: k_dp_sys does it
     uint32_t lo, hi;
     class_range(a.class_lo, CLS, total, lo, hi);
     const uint32_t n_threads = gridDim.x * DP_THREADS;
@@ -1135,6 +1137,131 @@ __global__ __launch_bounds__(DP_THREADS) void k_dp_regs(DpArgs a)
         good = false;
 #endif
         if (live) atomicAdd(&a.counts[(good ? a.n_paths : 0) + e.p], 1u);
+    }
+}
+
+// Short worklists (the batches a search submits: a few thousand pairs) are bound
+// by the latency of the longest single fill, not by throughput: a 900-step path
+// against a 16-step alignment is 14 400 dependent cells for one lane of
+// k_dp_regs.  k_dp_sys turns the table sideways: one column per lane, the rows
+// stream through as a wavefront.  At step s lane c fills cell (i = s - c,
+// j = c + 1); the cell to its left (i, j-1) is its left neighbour's result of
+// step s-1, fetched with one DPP shift (zero shifted in = column 0, which the
+// reference never writes), the diagonal one (i-1, j-1) is what it fetched the
+// step before.  A fill takes n + m steps of ~15 instructions instead of n * m
+// cells of 12; throughput is lower (idle columns), so long lists keep
+// k_dp_regs.  MC = 16: four pairs per wave (DPP rows), MC = 64: one.
+constexpr int SYS_MAX_M = 64;
+
+template <int MC>
+__device__ __forceinline__ int from_left_column(int v)
+{
+    // row_shr:1 within 16-lane rows / wave_shr:1; lanes without a source read 0
+    return MC == 16 ? __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true)
+                    : __builtin_amdgcn_update_dpp(0, v, 0x138, 0xF, 0xF, true);
+}
+
+// One wavefront step of k_dp_sys for this lane's column j: (d_dp, d_x) is the
+// diagonal cell, the left one is fetched into (r_dp, r_x) for the next step.
+template <int MC>
+__device__ __forceinline__ void sys_step(int s, int j, int n, uint32_t b, int up_cost,
+                                         const uint16_t *arow, uint32_t &a_next, int &l_dp,
+                                         int &l_x, int d_dp, int d_x, int &r_dp, int &r_x)
+{
+    r_dp = from_left_column<MC>(l_dp);
+    r_x = from_left_column<MC>(l_x);
+    const uint32_t ai = a_next;
+    a_next = arow[s + 1];
+    if ((unsigned)(s - j) < (unsigned)n) {     // row i = s - c is in 1..n
+        const int d = d_dp + ((ai == b) ? 0 : -1);
+        const int u = l_dp + up_cost;
+        const int lf = r_dp - 1;
+        const int v = max(d, max(u, lf));
+        const int xx = (v == d) ? d_x : ((l_dp >= r_dp) ? l_x : r_x);   // :527, 534, 541
+        l_dp = v;
+        l_x = xx;
+    }
+}
+
+template <int MC>
+__global__ __launch_bounds__(DP_THREADS) void k_dp_sys(DpArgs a)
+{
+    static_assert(MC == 16 || MC == 64, "group = DPP row or whole wave");
+    constexpr int G = WAVE / MC;                          // pairs per wave
+    constexpr int PAD = MC;                               // reads of idle lanes stay inside
+    __shared__ uint16_t apath[G][GFAL_MAX_STEPS + 2 * PAD + 8];
+    if (*a.wl_count > a.wl_capacity) return;              // overflow: see k_wl_scatter
+    const uint32_t total = *a.wl_count;
+    if (total > a.sys_limit) return;                      // long list: k_dp_regs / k_dp_long
+    // MC = 16: classes 0..2 (up to 16 steps); MC = 64: class 3 and the entries
+    // of the last class that fit (k_dp_long skips those on a short list)
+    const uint32_t lo = min(a.class_lo[MC == 16 ? 0 : 3], total);
+    const uint32_t hi = MC == 16 ? min(a.class_lo[3], total) : total;
+    const int lane = threadIdx.x;
+    const int c = lane % MC, g = lane / MC;
+    const int j = c + 1;
+    for (uint32_t w0 = lo + blockIdx.x * G; w0 < hi; w0 += gridDim.x * G) {
+        const uint32_t w = w0 + g;
+        const DpEntry e = load_entry(a, w, w < hi);
+        const bool live = w < hi && e.m <= MC;
+        // stage the groups' paths (neighbouring entries usually share one)
+        __syncthreads();
+        int my_row = g;
+        {
+            uint32_t prev_p = 0xFFFFFFFFu;
+            int prev_row = 0;
+#pragma unroll
+            for (int gg = 0; gg < G; ++gg) {
+                const uint32_t p_gg = (uint32_t)__builtin_amdgcn_readlane((int)e.p, gg * MC);
+                const int n_gg = __builtin_amdgcn_readlane(live ? e.n : 0, gg * MC);
+                int row = gg;
+                if (gg > 0 && p_gg == prev_p && n_gg > 0) {
+                    row = prev_row;
+                } else if (n_gg > 0) {
+                    const uint16_t *src = a.images + (size_t)p_gg * a.L.total + a.L.step_at();
+                    for (int i = lane; i < n_gg; i += WAVE) apath[gg][PAD + i] = src[i];
+                    prev_p = p_gg;
+                    prev_row = gg;
+                }
+                if (g == gg) my_row = row;
+            }
+        }
+        __syncthreads();
+        const uint16_t *arow = apath[my_row] + PAD - 1 - c;    // arow[s] = step of row s - c
+
+        bool good = false;
+        for (int pass = 0; pass < 2; ++pass) {
+            // pass 0: the forward orientation if flagged, else the reverse one;
+            // pass 1: the reverse one for pairs with both flags
+            const bool run = live && (pass == 0 || (e.has_fw && e.has_rc));
+            if (!WAVE_ANY(run)) break;
+            const bool flip = pass == 1 || !e.has_fw;
+            const int n = run ? e.n : 0, m = e.m;
+            uint32_t b = STEP_INVALID;
+            if (run && c < m)
+                b = flip ? ((uint32_t)e.bp[(m - 1 - c) * WAVE] ^ 1u) : (uint32_t)e.bp[c * WAVE];
+            const int up_cost = (j < m) ? -1 : 0;         // :504 free in the last column
+            // row 0 of my column (:500; m <= n here, so every column is inside)
+            int l_dp = -j, l_x = -j;                      // my latest cell (i - 1, j)
+            int g_dp = 0, g_x = 0;                        // the diagonal one (i - 1, j - 1)
+            int n_max = 0;
+#pragma unroll
+            for (int gg = 0; gg < G; ++gg) n_max = max(n_max, __builtin_amdgcn_readlane(n, gg * MC));
+            // two steps per trip: what was fetched from the left in one step is
+            // the diagonal of the next, so the roles of (g, h) alternate; the
+            // path step of the next row is loaded one step ahead
+            uint32_t a_next = arow[1];
+            for (int s = 1; s < n_max + MC; s += 2) {
+                int h_dp, h_x;
+                sys_step<MC>(s, j, n, b, up_cost, arow, a_next, l_dp, l_x, g_dp, g_x, h_dp, h_x);
+                sys_step<MC>(s + 1, j, n, b, up_cost, arow, a_next, l_dp, l_x, h_dp, h_x, g_dp, g_x);
+            }
+            // lane m-1 of the group holds cell (n, m)
+            good |= run && c == m - 1 && l_dp == l_x;
+        }
+        const lanemask gm = WAVE_MASK(good);
+        const lanemask mine = (gm >> (g * MC)) & ((MC == 64) ? ~0ull : ((1ull << MC) - 1ull));
+        if (live && c == 0) atomicAdd(&a.counts[(mine != 0 ? a.n_paths : 0) + e.p], 1u);
     }
 }
 
@@ -1153,15 +1280,17 @@ __global__ __launch_bounds__(DP_THREADS) void k_dp_long(DpArgs a)
         const uint32_t w = w0 + threadIdx.x;
         const bool live = w < hi;
         const DpEntry e = load_entry(a, w, live);
+        // on a short list k_dp_sys<64> takes the entries of up to 64 steps
+        const bool mine = live && !(total <= a.sys_limit && e.m <= SYS_MAX_M);
         // src/eval.cpp:92-98; both fills always run so the lanes of the wave
         // stay in step through the row loops (a dead lane has n = m = 0)
-        StepsA A{e.astep, e.n};
-        StepsB B{e.bp, e.m, 0u};
+        StepsA A{e.astep, mine ? e.n : 0};
+        StepsB B{e.bp, mine ? e.m : 0, 0u};
         const int fw = traceback_score(A, B, row, stride);
         B.flip = 1u;
         const int rc = traceback_score(A, B, row, stride);
         const bool good = fw == 0 || rc == 0;
-        if (live) atomicAdd(&a.counts[(good ? a.n_paths : 0) + e.p], 1u);
+        if (mine) atomicAdd(&a.counts[(good ? a.n_paths : 0) + e.p], 1u);
     }
 }
 
@@ -1203,6 +1332,7 @@ __global__ void k_fill_i32(int32_t *p, long long n, int32_t v)
 // --------------------------------------------------------------------------
 struct gfal_scorer {
     int device = 0;
+    int n_cus = 256;
     int64_t n_aln = 0, n_steps = 0;
     int32_t n_nodes = 0, n_local = 0, max_aln_len = 0;
     uint32_t n_empty = 0;
@@ -1222,6 +1352,7 @@ struct gfal_scorer {
     unsigned long long *d_worklist = nullptr;   // as pushed by k_scan
     unsigned long long *d_worklist_sorted = nullptr;
     uint32_t wl_capacity = 0;
+    uint32_t dp_sys_limit = 65536;   // see k_dp_sys
     uint32_t *d_len_bins = nullptr;    // [3 * LEN_BINS] path-length counting sort
     int32_t *d_order = nullptr;        // [n_paths] slot -> caller's path index
     uint32_t *d_counts_slot = nullptr; // [3 * n_paths] counters by slot
@@ -1600,6 +1731,7 @@ int gfal_scorer_create_ex(const int32_t *aln_off, const int32_t *aln_steps,
         }                                                                      \
     } while (0)
     CREATE_TRY(hipSetDevice(device));
+    CREATE_TRY(hipDeviceGetAttribute(&s->n_cus, hipDeviceAttributeMultiprocessorCount, device));
     CREATE_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     CREATE_TRY(hipEventCreateWithFlags(&s->dp_fork, hipEventDisableTiming));
     for (int i = 0; i < 3; ++i) {
@@ -1625,6 +1757,7 @@ int gfal_scorer_create_ex(const int32_t *aln_off, const int32_t *aln_steps,
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_status), 4 * sizeof(uint32_t)));
     CREATE_TRY(hipMemset(s->d_status, 0, 4 * sizeof(uint32_t)));
     // worklist: at least one entry per alignment, so a single path always fits
+    if (const char *env = getenv("GFAL_DP_SYS_LIMIT")) s->dp_sys_limit = (uint32_t)atoll(env);
     s->wl_capacity = (uint32_t)std::max<int64_t>(n_aln, (int64_t)1 << 22);
     if (const char *env = getenv("GFAL_DEBUG_WL_CAPACITY"))   // tests: force the overflow path
         s->wl_capacity = (uint32_t)std::max<int64_t>(n_aln, atoll(env));
@@ -1745,8 +1878,22 @@ int gfal_scorer_score_device(gfal_scorer *s, const int32_t *d_path_off,
         int chunks = (want_groups + a.n_tiles - 1) / a.n_tiles;
         // at least ~50 items per wave and workgroup: every workgroup re-stages its
         // tile's images, which small shards cannot amortise otherwise
+        const int want_chunks = chunks;
         const int max_chunks = std::max(1, s->n_items / (50 * SCAN_WAVES));
         chunks = std::max(1, std::min(chunks, max_chunks));
+        // small batches (what a search submits) end up with about one round of the
+        // 2-per-CU resident workgroups, and tiles of long paths cost more than
+        // tiles of short ones: trade staging for balance down to ~12 items per
+        // wave until there are four rounds, and always fill the first round
+        const int slots = 2 * s->n_cus;
+        if ((long long)a.n_tiles * chunks < 4LL * slots) {
+            const int balanced = std::min((4 * slots + a.n_tiles - 1) / a.n_tiles,
+                                          std::max(1, s->n_items / (12 * SCAN_WAVES)));
+            chunks = std::max(chunks, std::min(want_chunks, balanced));
+        }
+        if ((long long)a.n_tiles * chunks < slots)
+            chunks = std::max(chunks, std::min(slots / a.n_tiles,
+                                               std::max(1, s->n_items / SCAN_WAVES)));
         a.n_chunks = chunks;
         a.filter = filter ? 1 : 0;
         a.counts = d_counts;
@@ -1779,6 +1926,7 @@ int gfal_scorer_score_device(gfal_scorer *s, const int32_t *d_path_off,
         d.class_lo = d_class_lo;
         d.wl_count = s->d_status + 1;
         d.wl_capacity = s->wl_capacity;
+        d.sys_limit = s->dp_sys_limit;
         d.row_scratch = s->d_rows;
         d.counts = d_counts;
         // fork: classes 8 / 16 / 32+ on side streams, class 4 on the caller's
@@ -1789,6 +1937,9 @@ int gfal_scorer_score_device(gfal_scorer *s, const int32_t *d_path_off,
             forked |= 1 << i;
             return s->dp_stream[i];
         };
+        // every kernel of both families is launched; the list length (known on
+        // the device only) decides which family returns at once
+        hipLaunchKernelGGL(k_dp_sys<16>, dim3(DP_REG_BLOCKS), dim3(DP_THREADS), 0, st, d);
         hipLaunchKernelGGL((k_dp_regs<4, 0>), dim3(DP_REG_BLOCKS), dim3(DP_THREADS), 0, st, d);
         if (s->max_aln_len > 4)
             hipLaunchKernelGGL((k_dp_regs<8, 1>), dim3(DP_REG_BLOCKS), dim3(DP_THREADS), 0,
@@ -1798,6 +1949,7 @@ int gfal_scorer_score_device(gfal_scorer *s, const int32_t *d_path_off,
                                side(1), d);
         if (s->max_aln_len > 16) {
             hipStream_t s2 = side(2);
+            hipLaunchKernelGGL(k_dp_sys<64>, dim3(DP_REG_BLOCKS), dim3(DP_THREADS), 0, s2, d);
             hipLaunchKernelGGL((k_dp_regs<32, 3>), dim3(DP_REG_BLOCKS), dim3(DP_THREADS), 0, s2, d);
             if (s->max_aln_len > 32) {
                 if (dp_rows_fit_lds(s->max_aln_len))
