@@ -51,7 +51,7 @@ constexpr int LDS_BUDGET = 80 * 1024;  // k_scan: two workgroups per CU (160 KiB
 constexpr int LDS_MAX = 160 * 1024;
 constexpr int DP_THREADS = 64;
 constexpr int DP_BLOCKS = 512;        // row-scratch kernels (k_dp_long, k_pairs)
-constexpr int DP_REG_BLOCKS = 4096;   // register-row kernels: 4 waves per SIMD
+constexpr int DP_REG_BLOCKS = 4096, DP_SYS_BLOCKS = 2048;   // register-row kernels: 4 waves per SIMD
 
 // Chain entries (first[] / next[]): position | ENT_NEG.  The two terminal
 // values decode to positions 1023 / 1022, which no window test accepts.
@@ -314,12 +314,48 @@ __global__ void k_len_scatter(const int32_t *__restrict__ path_off, int n_paths,
     order[bins[LEN_BINS + b] + atomicAdd(&bins[2 * LEN_BINS + b], 1u)] = p;
 }
 
+// The three steps above in one workgroup (bins in LDS): batches of up to a few
+// ten thousand paths, where two extra launches cost more than the sort.
+__global__ __launch_bounds__(LEN_BINS) void k_len_sort_block(
+    const int32_t *__restrict__ path_off, int n_paths, int32_t *__restrict__ order,
+    uint32_t *__restrict__ zero_a, int n_a, uint32_t *__restrict__ zero_b, int n_b)
+{
+    __shared__ uint32_t count[LEN_BINS], part[LEN_BINS], cursor[LEN_BINS];
+    const int tid = threadIdx.x;
+    // also clears the per-call accumulators (instead of two memsets)
+    for (int i = tid; i < n_a; i += LEN_BINS) zero_a[i] = 0;
+    for (int i = tid; i < n_b; i += LEN_BINS) zero_b[i] = 0;
+    count[tid] = 0;
+    cursor[tid] = 0;
+    __syncthreads();
+    for (int p = tid; p < n_paths; p += LEN_BINS) atomicAdd(&count[length_bin(path_off, p)], 1u);
+    __syncthreads();
+    const uint32_t mine = count[tid];
+    part[tid] = mine;
+    __syncthreads();
+    for (int o = 1; o < LEN_BINS; o <<= 1) {
+        uint32_t v = tid >= o ? part[tid - o] : 0u;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    part[tid] -= mine;
+    __syncthreads();
+    for (int p = tid; p < n_paths; p += LEN_BINS) {
+        const int b = length_bin(path_off, p);
+        order[part[b] + atomicAdd(&cursor[b], 1u)] = p;
+    }
+}
+
 // counters by slot -> counters by caller's path index
 __global__ void k_unpermute(const uint32_t *__restrict__ by_slot,
                             const int32_t *__restrict__ order, int n_paths,
-                            uint32_t *__restrict__ out)
+                            uint32_t *__restrict__ out, const uint32_t *__restrict__ status,
+                            uint32_t *__restrict__ status_copy)
 {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    // blocking API: the status words travel with the counters (one copy out)
+    if (status_copy && q < 4) status_copy[q] = status[q];
     if (q >= n_paths) return;
     const int p = order[q];
     out[p] = by_slot[q];
@@ -1150,78 +1186,97 @@ __global__ __launch_bounds__(DP_THREADS) void k_dp_regs(DpArgs a)
 // reference never writes), the diagonal one (i-1, j-1) is what it fetched the
 // step before.  A fill takes n + m steps of ~15 instructions instead of n * m
 // cells of 12; throughput is lower (idle columns), so long lists keep
-// k_dp_regs.  MC = 16: four pairs per wave (DPP rows), MC = 64: one.
+// k_dp_regs.  MC lanes per pair: 4, 8, 16 (shifts inside DPP rows) or 64.
 constexpr int SYS_MAX_M = 64;
 
 template <int MC>
-__device__ __forceinline__ int from_left_column(int v)
+__device__ __forceinline__ int from_left_column(int v, bool first_column)
 {
-    // row_shr:1 within 16-lane rows / wave_shr:1; lanes without a source read 0
-    return MC == 16 ? __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true)
-                    : __builtin_amdgcn_update_dpp(0, v, 0x138, 0xF, 0xF, true);
+    // row_shr:1 within 16-lane rows / wave_shr:1; lanes without a source read 0,
+    // and so must the first lane of a group that starts inside a row
+    const int r = MC <= 16 ? __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true)
+                           : __builtin_amdgcn_update_dpp(0, v, 0x138, 0xF, 0xF, true);
+    return (MC < 16 && first_column) ? 0 : r;
 }
 
 // One wavefront step of k_dp_sys for this lane's column j: (d_dp, d_x) is the
-// diagonal cell, the left one is fetched into (r_dp, r_x) for the next step.
+// diagonal cell; the left one is fetched into (r_dp, r_x) and is the diagonal
+// of the next step.  (A lone wave issues one instruction every ~4.5 cycles
+// whatever the dependencies: running both orientations in one lane doubled the
+// step time, so they go to different lane groups instead.)
 template <int MC>
 __device__ __forceinline__ void sys_step(int s, int j, int n, uint32_t b, int up_cost,
                                          const uint16_t *arow, uint32_t &a_next, int &l_dp,
                                          int &l_x, int d_dp, int d_x, int &r_dp, int &r_x)
 {
-    r_dp = from_left_column<MC>(l_dp);
-    r_x = from_left_column<MC>(l_x);
+    r_dp = from_left_column<MC>(l_dp, j == 1);
+    r_x = from_left_column<MC>(l_x, j == 1);
     const uint32_t ai = a_next;
     a_next = arow[s + 1];
-    if ((unsigned)(s - j) < (unsigned)n) {     // row i = s - c is in 1..n
-        const int d = d_dp + ((ai == b) ? 0 : -1);
-        const int u = l_dp + up_cost;
-        const int lf = r_dp - 1;
-        const int v = max(d, max(u, lf));
-        const int xx = (v == d) ? d_x : ((l_dp >= r_dp) ? l_x : r_x);   // :527, 534, 541
-        l_dp = v;
-        l_x = xx;
-    }
+    // selects, not a branch: the exec-mask round trip through the scalar unit
+    // costs a lone wave more than the two extra instructions
+    const bool active = (unsigned)(s - j) < (unsigned)n;     // row i = s - c is in 1..n
+    const int d = d_dp + ((ai == b) ? 0 : -1);
+    const int u = l_dp + up_cost;
+    const int v = max(d, max(u, r_dp - 1));
+    const int xx = (v == d) ? d_x : ((l_dp >= r_dp) ? l_x : r_x);   // :527, 534, 541
+    l_x = active ? xx : l_x;
+    l_dp = active ? v : l_dp;
 }
 
 template <int MC>
 __global__ __launch_bounds__(DP_THREADS) void k_dp_sys(DpArgs a)
 {
-    static_assert(MC == 16 || MC == 64, "group = DPP row or whole wave");
-    constexpr int G = WAVE / MC;                          // pairs per wave
+    static_assert(MC == 4 || MC == 8 || MC == 16 || MC == 64, "group inside a DPP row, or the wave");
+    constexpr int G = WAVE / MC;                          // lane groups (fills) per wave
+    // MC < 64: an entry takes two neighbouring groups, one per orientation;
+    // MC = 64: one entry per wave, the orientations one after the other
+    constexpr int ENTRIES = MC == 64 ? 1 : G / 2;
     constexpr int PAD = MC;                               // reads of idle lanes stay inside
     __shared__ uint16_t apath[G][GFAL_MAX_STEPS + 2 * PAD + 8];
     if (*a.wl_count > a.wl_capacity) return;              // overflow: see k_wl_scatter
     const uint32_t total = *a.wl_count;
     if (total > a.sys_limit) return;                      // long list: k_dp_regs / k_dp_long
-    // MC = 16: classes 0..2 (up to 16 steps); MC = 64: class 3 and the entries
-    // of the last class that fit (k_dp_long skips those on a short list)
-    const uint32_t lo = min(a.class_lo[MC == 16 ? 0 : 3], total);
-    const uint32_t hi = MC == 16 ? min(a.class_lo[3], total) : total;
+    // MC = 4, 8, 16: classes 0, 1, 2; MC = 64: class 3 and the entries of the
+    // last class that fit (k_dp_long skips those on a short list)
+    constexpr int CLS = MC == 4 ? 0 : MC == 8 ? 1 : MC == 16 ? 2 : 3;
+    const uint32_t lo = min(a.class_lo[CLS], total);
+    const uint32_t hi = MC == 64 ? total : min(a.class_lo[CLS + 1], total);
     const int lane = threadIdx.x;
     const int c = lane % MC, g = lane / MC;
     const int j = c + 1;
-    for (uint32_t w0 = lo + blockIdx.x * G; w0 < hi; w0 += gridDim.x * G) {
-        const uint32_t w = w0 + g;
+    for (uint32_t w0 = lo + blockIdx.x * ENTRIES; w0 < hi; w0 += gridDim.x * ENTRIES) {
+        const uint32_t w = w0 + (MC == 64 ? 0 : g / 2);
         const DpEntry e = load_entry(a, w, w < hi);
         const bool live = w < hi && e.m <= MC;
-        // stage the groups' paths (neighbouring entries usually share one)
+        // stage the groups' paths with the whole wave, all loads of a path in
+        // flight at once; neighbouring groups usually share the path (the two
+        // orientations of an entry always do) and then share the copy
         __syncthreads();
         int my_row = g;
         {
             uint32_t prev_p = 0xFFFFFFFFu;
             int prev_row = 0;
-#pragma unroll
             for (int gg = 0; gg < G; ++gg) {
                 const uint32_t p_gg = (uint32_t)__builtin_amdgcn_readlane((int)e.p, gg * MC);
                 const int n_gg = __builtin_amdgcn_readlane(live ? e.n : 0, gg * MC);
                 int row = gg;
-                if (gg > 0 && p_gg == prev_p && n_gg > 0) {
-                    row = prev_row;
-                } else if (n_gg > 0) {
-                    const uint16_t *src = a.images + (size_t)p_gg * a.L.total + a.L.step_at();
-                    for (int i = lane; i < n_gg; i += WAVE) apath[gg][PAD + i] = src[i];
-                    prev_p = p_gg;
-                    prev_row = gg;
+                if (n_gg > 0) {
+                    if (p_gg == prev_p) {
+                        row = prev_row;
+                    } else {
+                        const uint16_t *src = a.images + (size_t)p_gg * a.L.total + a.L.step_at();
+                        constexpr int LOADS = (GFAL_MAX_STEPS + WAVE - 1) / WAVE;
+                        uint16_t t[LOADS];
+#pragma unroll
+                        for (int k = 0; k < LOADS; ++k)
+                            t[k] = (lane + k * WAVE < n_gg) ? src[lane + k * WAVE] : (uint16_t)0;
+#pragma unroll
+                        for (int k = 0; k < LOADS; ++k)
+                            if (lane + k * WAVE < n_gg) apath[gg][PAD + lane + k * WAVE] = t[k];
+                        prev_p = p_gg;
+                        prev_row = gg;
+                    }
                 }
                 if (g == gg) my_row = row;
             }
@@ -1230,12 +1285,12 @@ __global__ __launch_bounds__(DP_THREADS) void k_dp_sys(DpArgs a)
         const uint16_t *arow = apath[my_row] + PAD - 1 - c;    // arow[s] = step of row s - c
 
         bool good = false;
-        for (int pass = 0; pass < 2; ++pass) {
-            // pass 0: the forward orientation if flagged, else the reverse one;
-            // pass 1: the reverse one for pairs with both flags
-            const bool run = live && (pass == 0 || (e.has_fw && e.has_rc));
-            if (!WAVE_ANY(run)) break;
-            const bool flip = pass == 1 || !e.has_fw;
+        for (int pass = 0; pass < (MC == 64 ? 2 : 1); ++pass) {
+            const bool flip = MC == 64 ? pass == 1 : (g & 1) != 0;
+            // orientations the scan did not flag cannot be free (DESIGN.md
+            // section 2): their group idles
+            const bool run = live && (flip ? e.has_rc : e.has_fw);
+            if (!WAVE_ANY(run)) continue;
             const int n = run ? e.n : 0, m = e.m;
             uint32_t b = STEP_INVALID;
             if (run && c < m)
@@ -1244,9 +1299,10 @@ __global__ __launch_bounds__(DP_THREADS) void k_dp_sys(DpArgs a)
             // row 0 of my column (:500; m <= n here, so every column is inside)
             int l_dp = -j, l_x = -j;                      // my latest cell (i - 1, j)
             int g_dp = 0, g_x = 0;                        // the diagonal one (i - 1, j - 1)
-            int n_max = 0;
+            int n_max = n;
 #pragma unroll
-            for (int gg = 0; gg < G; ++gg) n_max = max(n_max, __builtin_amdgcn_readlane(n, gg * MC));
+            for (int o = MC; o < WAVE; o <<= 1) n_max = max(n_max, __shfl_xor(n_max, o, WAVE));
+            n_max = __builtin_amdgcn_readfirstlane(n_max);
             // two steps per trip: what was fetched from the left in one step is
             // the diagonal of the next, so the roles of (g, h) alternate; the
             // path step of the next row is loaded one step ahead
@@ -1259,9 +1315,11 @@ __global__ __launch_bounds__(DP_THREADS) void k_dp_sys(DpArgs a)
             // lane m-1 of the group holds cell (n, m)
             good |= run && c == m - 1 && l_dp == l_x;
         }
+        // the entry's lanes: both of its groups
+        constexpr int SPAN = MC == 64 ? 64 : 2 * MC;
         const lanemask gm = WAVE_MASK(good);
-        const lanemask mine = (gm >> (g * MC)) & ((MC == 64) ? ~0ull : ((1ull << MC) - 1ull));
-        if (live && c == 0) atomicAdd(&a.counts[(mine != 0 ? a.n_paths : 0) + e.p], 1u);
+        const lanemask mine = (gm >> (lane / SPAN * SPAN)) & (SPAN == 64 ? ~0ull : ((1ull << SPAN) - 1ull));
+        if (live && lane % SPAN == 0) atomicAdd(&a.counts[(mine != 0 ? a.n_paths : 0) + e.p], 1u);
     }
 }
 
@@ -1367,6 +1425,11 @@ struct gfal_scorer {
     int32_t *d_path_off = nullptr, *d_path_steps = nullptr;
     uint32_t *d_counts = nullptr;
     size_t path_off_cap = 0, path_steps_cap = 0, counts_cap = 0;
+    // blocking API: pinned staging, one copy in ([offsets | steps] -> d_path_off)
+    // and one out ([counters | status words] <- d_counts)
+    int32_t *h_in = nullptr;
+    uint32_t *h_out = nullptr;
+    size_t h_in_cap = 0, h_out_cap = 0;
     hipStream_t stream = nullptr;      // owned, for the blocking API
     // the DP kernels of the different length classes run side by side: each is
     // bound by the latency of its longest single fill, not by throughput
@@ -1410,6 +1473,18 @@ int dev_reserve(T **buf, size_t *cap, size_t want)
     return GFAL_OK;
 }
 
+template <typename T>
+int pinned_reserve(T **buf, size_t *cap, size_t want)
+{
+    if (want <= *cap && *buf) return GFAL_OK;
+    if (*buf) HIP_TRY(hipHostFree(*buf));
+    *buf = nullptr;
+    size_t grow = std::max<size_t>(want + want / 2, 1024);
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(buf), grow * sizeof(T), hipHostMallocDefault));
+    *cap = grow;
+    return GFAL_OK;
+}
+
 void free_scorer(gfal_scorer *s)
 {
     if (!s) return;
@@ -1423,6 +1498,8 @@ void free_scorer(gfal_scorer *s)
                     s->d_counts};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
+    if (s->h_in) (void)hipHostFree(s->h_in);
+    if (s->h_out) (void)hipHostFree(s->h_out);
     for (auto &set : s->ev)
         for (hipEvent_t e : set)
             if (e) (void)hipEventDestroy(e);
@@ -1789,10 +1866,10 @@ int gfal_scorer_set_profiling(gfal_scorer *s, int enable)
     return GFAL_OK;
 }
 
-int gfal_scorer_score_device(gfal_scorer *s, const int32_t *d_path_off,
+static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
                              const int32_t *d_path_steps, int32_t n_paths,
                              int64_t total_steps, int32_t max_path_len, int filter,
-                             uint32_t *d_counts, void *hip_stream)
+                             uint32_t *d_counts, void *hip_stream, uint32_t *status_copy)
 {
     if (!s || n_paths < 0 || total_steps < 0) return GFAL_E_ARG;
     if (n_paths == 0) return GFAL_OK;
@@ -1829,9 +1906,11 @@ int gfal_scorer_score_device(gfal_scorer *s, const int32_t *d_path_off,
     uint32_t *d_hist = s->d_wl_bins, *d_offsets = s->d_wl_bins + n_bins,
              *d_cursor = s->d_wl_bins + 2 * (size_t)n_bins,
              *d_class_lo = s->d_wl_bins + 3 * (size_t)n_bins;
-    HIP_TRY(hipMemsetAsync(d_hist, 0, (size_t)n_bins * sizeof(uint32_t), st));
-
-    HIP_TRY(hipMemsetAsync(s->d_status, 0, 4 * sizeof(uint32_t), st));
+    const bool one_block_sort = n_paths <= 32768;   // k_len_sort_block also clears these
+    if (!one_block_sort) {
+        HIP_TRY(hipMemsetAsync(d_hist, 0, (size_t)n_bins * sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(s->d_status, 0, 4 * sizeof(uint32_t), st));
+    }
     hipEvent_t *ev = s->ev[s->ev_calls % gfal_scorer::EV_RING];
     if (s->profiling) HIP_TRY(hipEventRecord(ev[0], st));
 
@@ -1841,12 +1920,17 @@ int gfal_scorer_score_device(gfal_scorer *s, const int32_t *d_path_off,
     const unsigned p_blocks = (unsigned)((n_paths + 255) / 256);
     uint32_t *const d_user_counts = d_counts;
     d_counts = s->d_counts_slot;
-    HIP_TRY(hipMemsetAsync(s->d_len_bins, 0, LEN_BINS * sizeof(uint32_t), st));
-    hipLaunchKernelGGL(k_len_hist, dim3(p_blocks), dim3(256), 0, st, d_path_off, (int)n_paths,
-                       s->d_len_bins);
-    hipLaunchKernelGGL(k_len_offsets, dim3(1), dim3(LEN_BINS), 0, st, s->d_len_bins);
-    hipLaunchKernelGGL(k_len_scatter, dim3(p_blocks), dim3(256), 0, st, d_path_off,
-                       (int)n_paths, s->d_len_bins, s->d_order);
+    if (one_block_sort) {
+        hipLaunchKernelGGL(k_len_sort_block, dim3(1), dim3(LEN_BINS), 0, st, d_path_off,
+                           (int)n_paths, s->d_order, d_hist, n_bins, s->d_status, 4);
+    } else {
+        HIP_TRY(hipMemsetAsync(s->d_len_bins, 0, LEN_BINS * sizeof(uint32_t), st));
+        hipLaunchKernelGGL(k_len_hist, dim3(p_blocks), dim3(256), 0, st, d_path_off,
+                           (int)n_paths, s->d_len_bins);
+        hipLaunchKernelGGL(k_len_offsets, dim3(1), dim3(LEN_BINS), 0, st, s->d_len_bins);
+        hipLaunchKernelGGL(k_len_scatter, dim3(p_blocks), dim3(256), 0, st, d_path_off,
+                           (int)n_paths, s->d_len_bins, s->d_order);
+    }
     hipLaunchKernelGGL(k_prep, dim3((unsigned)n_paths), dim3(WAVE), prep_lds, st,
                        d_path_off, d_path_steps, (int)n_paths, total_steps,
                        (int)max_path_len, s->d_node_local, (int)s->n_nodes,
@@ -1939,17 +2023,21 @@ int gfal_scorer_score_device(gfal_scorer *s, const int32_t *d_path_off,
         };
         // every kernel of both families is launched; the list length (known on
         // the device only) decides which family returns at once
-        hipLaunchKernelGGL(k_dp_sys<16>, dim3(DP_REG_BLOCKS), dim3(DP_THREADS), 0, st, d);
+        hipLaunchKernelGGL(k_dp_sys<4>, dim3(DP_SYS_BLOCKS), dim3(DP_THREADS), 0, st, d);
         hipLaunchKernelGGL((k_dp_regs<4, 0>), dim3(DP_REG_BLOCKS), dim3(DP_THREADS), 0, st, d);
-        if (s->max_aln_len > 4)
-            hipLaunchKernelGGL((k_dp_regs<8, 1>), dim3(DP_REG_BLOCKS), dim3(DP_THREADS), 0,
-                               side(0), d);
-        if (s->max_aln_len > 8)
-            hipLaunchKernelGGL((k_dp_regs<16, 2>), dim3(DP_REG_BLOCKS), dim3(DP_THREADS), 0,
-                               side(1), d);
+        if (s->max_aln_len > 4) {
+            hipStream_t s0 = side(0);
+            hipLaunchKernelGGL(k_dp_sys<8>, dim3(DP_SYS_BLOCKS), dim3(DP_THREADS), 0, s0, d);
+            hipLaunchKernelGGL((k_dp_regs<8, 1>), dim3(DP_REG_BLOCKS), dim3(DP_THREADS), 0, s0, d);
+        }
+        if (s->max_aln_len > 8) {
+            hipStream_t s1 = side(1);
+            hipLaunchKernelGGL(k_dp_sys<16>, dim3(DP_SYS_BLOCKS), dim3(DP_THREADS), 0, s1, d);
+            hipLaunchKernelGGL((k_dp_regs<16, 2>), dim3(DP_REG_BLOCKS), dim3(DP_THREADS), 0, s1, d);
+        }
         if (s->max_aln_len > 16) {
             hipStream_t s2 = side(2);
-            hipLaunchKernelGGL(k_dp_sys<64>, dim3(DP_REG_BLOCKS), dim3(DP_THREADS), 0, s2, d);
+            hipLaunchKernelGGL(k_dp_sys<64>, dim3(DP_SYS_BLOCKS), dim3(DP_THREADS), 0, s2, d);
             hipLaunchKernelGGL((k_dp_regs<32, 3>), dim3(DP_REG_BLOCKS), dim3(DP_THREADS), 0, s2, d);
             if (s->max_aln_len > 32) {
                 if (dp_rows_fit_lds(s->max_aln_len))
@@ -1970,7 +2058,7 @@ int gfal_scorer_score_device(gfal_scorer *s, const int32_t *d_path_off,
         HIP_TRY(hipEventRecord(ev[2], st));
     }
     hipLaunchKernelGGL(k_unpermute, dim3(p_blocks), dim3(256), 0, st, d_counts, s->d_order,
-                       (int)n_paths, d_user_counts);
+                       (int)n_paths, d_user_counts, s->d_status, status_copy);
     HIP_TRY(hipGetLastError());
     if (s->profiling) {
         HIP_TRY(hipEventRecord(ev[3], st));
@@ -1981,15 +2069,18 @@ int gfal_scorer_score_device(gfal_scorer *s, const int32_t *d_path_off,
     return GFAL_OK;
 }
 
-int gfal_scorer_sync_status(gfal_scorer *s)
+int gfal_scorer_score_device(gfal_scorer *s, const int32_t *d_path_off,
+                             const int32_t *d_path_steps, int32_t n_paths,
+                             int64_t total_steps, int32_t max_path_len, int filter,
+                             uint32_t *d_counts, void *hip_stream)
 {
-    if (!s) return GFAL_E_ARG;
-    if (!s->have_last) return GFAL_OK;
-    HIP_TRY(hipSetDevice(s->device));
-    uint32_t host[2] = {0, 0};
-    HIP_TRY(hipMemcpyAsync(host, s->d_status, sizeof(host), hipMemcpyDeviceToHost,
-                           s->last_stream));
-    HIP_TRY(hipStreamSynchronize(s->last_stream));
+    return score_device_impl(s, d_path_off, d_path_steps, n_paths, total_steps, max_path_len,
+                             filter, d_counts, hip_stream, nullptr);
+}
+
+// status words of a finished run -> return code
+static int status_to_code(const gfal_scorer *s, const uint32_t *host)
+{
     if (host[0] & (ST_BAD_LEN | ST_BAD_ID)) {
         set_err("device-side validation failed (status 0x%x)", host[0]);
         return GFAL_E_RANGE;
@@ -2002,6 +2093,18 @@ int gfal_scorer_sync_status(gfal_scorer *s)
     return GFAL_OK;
 }
 
+int gfal_scorer_sync_status(gfal_scorer *s)
+{
+    if (!s) return GFAL_E_ARG;
+    if (!s->have_last) return GFAL_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    uint32_t host[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(host, s->d_status, sizeof(host), hipMemcpyDeviceToHost,
+                           s->last_stream));
+    HIP_TRY(hipStreamSynchronize(s->last_stream));
+    return status_to_code(s, host);
+}
+
 static int score_range(gfal_scorer *s, const int32_t *path_off,
                        const int32_t *path_steps, int32_t lo, int32_t hi,
                        int32_t max_len, int filter, uint32_t *bad, uint32_t *good,
@@ -2010,22 +2113,23 @@ static int score_range(gfal_scorer *s, const int32_t *path_off,
     const int32_t P = hi - lo;
     const int64_t step0 = path_off[lo];
     const int64_t total = path_off[hi] - step0;
+    const size_t n_in = (size_t)P + 1 + (size_t)total, n_out = (size_t)3 * P + 4;
     int rc;
-    if ((rc = dev_reserve(&s->d_path_off, &s->path_off_cap, (size_t)P + 1))) return rc;
-    if ((rc = dev_reserve(&s->d_path_steps, &s->path_steps_cap, (size_t)total))) return rc;
-    if ((rc = dev_reserve(&s->d_counts, &s->counts_cap, (size_t)3 * P))) return rc;
-    std::vector<int32_t> off((size_t)P + 1);
-    for (int32_t i = 0; i <= P; ++i) off[(size_t)i] = (int32_t)(path_off[lo + i] - step0);
-    HIP_TRY(hipMemcpyAsync(s->d_path_off, off.data(), off.size() * sizeof(int32_t),
+    if ((rc = dev_reserve(&s->d_path_off, &s->path_off_cap, n_in))) return rc;
+    if ((rc = dev_reserve(&s->d_counts, &s->counts_cap, n_out))) return rc;
+    if ((rc = pinned_reserve(&s->h_in, &s->h_in_cap, n_in))) return rc;
+    if ((rc = pinned_reserve(&s->h_out, &s->h_out_cap, n_out))) return rc;
+    for (int32_t i = 0; i <= P; ++i) s->h_in[i] = (int32_t)(path_off[lo + i] - step0);
+    memcpy(s->h_in + P + 1, path_steps + step0, (size_t)total * sizeof(int32_t));
+    HIP_TRY(hipMemcpyAsync(s->d_path_off, s->h_in, n_in * sizeof(int32_t),
                            hipMemcpyHostToDevice, s->stream));
-    HIP_TRY(hipMemcpyAsync(s->d_path_steps, path_steps + step0,
-                           (size_t)total * sizeof(int32_t), hipMemcpyHostToDevice,
-                           s->stream));
-    HIP_TRY(hipStreamSynchronize(s->stream));   // `off` is a local
-    rc = gfal_scorer_score_device(s, s->d_path_off, s->d_path_steps, P, total, max_len,
-                                  filter, s->d_counts, s->stream);
+    rc = score_device_impl(s, s->d_path_off, s->d_path_off + P + 1, P, total, max_len, filter,
+                           s->d_counts, s->stream, s->d_counts + (size_t)3 * P);
     if (rc) return rc;
-    rc = gfal_scorer_sync_status(s);
+    HIP_TRY(hipMemcpyAsync(s->h_out, s->d_counts, n_out * sizeof(uint32_t),
+                           hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    rc = status_to_code(s, s->h_out + (size_t)3 * P);
     if (rc == GFAL_E_NOMEM && P > 1) {
         // worklist overflow: halve the batch (a single path always fits)
         int32_t mid = lo + P / 2;
@@ -2036,14 +2140,9 @@ static int score_range(gfal_scorer *s, const int32_t *path_off,
                            unaligned);
     }
     if (rc) return rc;
-    std::vector<uint32_t> host((size_t)3 * P);
-    HIP_TRY(hipMemcpy(host.data(), s->d_counts, host.size() * sizeof(uint32_t),
-                      hipMemcpyDeviceToHost));
-    for (int32_t i = 0; i < P; ++i) {
-        bad[lo + i] = host[(size_t)i];
-        good[lo + i] = host[(size_t)P + i];
-        if (unaligned) unaligned[lo + i] = host[(size_t)2 * P + i];
-    }
+    memcpy(bad + lo, s->h_out, (size_t)P * sizeof(uint32_t));
+    memcpy(good + lo, s->h_out + P, (size_t)P * sizeof(uint32_t));
+    if (unaligned) memcpy(unaligned + lo, s->h_out + (size_t)2 * P, (size_t)P * sizeof(uint32_t));
     return GFAL_OK;
 }
 

@@ -101,6 +101,26 @@ def test_fuzz_dp_length_classes(gpu, max_m, max_n):
         assert np.array_equal(g, e)
 
 
+@pytest.mark.parametrize("limit", ["0", "4000000000"])
+@pytest.mark.parametrize("max_m,max_n", [(7, 40), (30, 70), (64, 80), (90, 120)])
+def test_both_dp_kernel_families(gpu, monkeypatch, limit, max_m, max_n):
+    """The exact DP has a throughput family (one pair per lane, k_dp_regs /
+    k_dp_long) and a latency family (one column per lane, k_dp_sys) chosen by
+    the worklist length; force each on the same overhang-heavy inputs."""
+    rnd = random.Random(300 + max_m)
+    alns, paths = random_case(rnd, rnd.randint(2, 3), 900, 48, max_m, max_n,
+                              min_m=1, min_n=max(2, max_m // 2))
+    aoff, ast = csr(alns)
+    poff, pst = csr(paths)
+    monkeypatch.setenv("GFAL_DP_SYS_LIMIT", limit)
+    with Scorer(aoff, ast, 4) as sc:
+        got = sc.evaluate_paths(poff, pst, True)
+        assert sc.info()["dp_pairs"] > 300
+    exp = oracle.evaluate_paths(aoff, ast, poff, pst, True)
+    for g, e in zip(got, exp):
+        assert np.array_equal(g, e)
+
+
 def test_long_alignments_take_the_generic_path(gpu):
     """Alignments longer than the 16 register-resident steps."""
     rnd = random.Random(6)
