@@ -38,7 +38,7 @@ def build_scorer(force=False, verbose=False):
     if not force and not _stale(SCORER_SO, [src, hdr]):
         return SCORER_SO
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-I", INCLUDE, "-o", SCORER_SO, src]
+           "-pthread", "-I", INCLUDE, "-o", SCORER_SO, src]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -13,11 +13,18 @@
 #define GFALIGN_GRAPH_IO_H
 
 #include <cstdint>
+#include <cstring>
 #include <fstream>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 namespace gfal {
 
@@ -181,6 +188,177 @@ inline bool read_gaf(const std::string &file, std::vector<GafRecord> &out, std::
                 r.tags.push_back(t[0].substr(0, 2) + ":" + t[1].substr(0, 1) + ":" + t[2]);
         }
         out.push_back(std::move(r));
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------
+// `search` needs one thing from the GAF: the path column of every record as
+// packed steps (reference src/eval.cpp:123 getPaths -> src/alignments.cpp:75-94).
+// This reader maps the file, cuts it into line-aligned pieces and parses them on
+// several threads straight into the CSR the scorer takes; no GafRecord is built.
+// It accepts and rejects the same files as read_gaf (12 columns, the numeric
+// columns must parse as std::stoi would) and yields exactly what
+// PackedAlignments::add yields record by record.
+// ---------------------------------------------------------------------------
+class HeaderIndex {     // header -> uId without building std::string keys
+public:
+    explicit HeaderIndex(const Graph &g) : g_(g)
+    {
+        size_t cap = 16;
+        while (cap < 2 * g.headers.size() + 1) cap <<= 1;
+        slot_.assign(cap, -1);
+        for (size_t u = 0; u < g.headers.size(); ++u) {
+            size_t at = hash(g.headers[u].data(), g.headers[u].size()) & (cap - 1);
+            while (slot_[at] >= 0) at = (at + 1) & (cap - 1);
+            slot_[at] = (int32_t)u;
+        }
+    }
+    // unknown names alias uId 0, as Graph::id_or_zero does
+    uint32_t id_or_zero(const char *p, size_t n) const
+    {
+        size_t at = hash(p, n) & (slot_.size() - 1);
+        while (slot_[at] >= 0) {
+            const std::string &h = g_.headers[(size_t)slot_[at]];
+            if (h.size() == n && memcmp(h.data(), p, n) == 0) return (uint32_t)slot_[at];
+            at = (at + 1) & (slot_.size() - 1);
+        }
+        return 0;
+    }
+
+private:
+    static size_t hash(const char *p, size_t n)
+    {
+        uint64_t h = 1469598103934665603ull;     // FNV-1a
+        for (size_t i = 0; i < n; ++i) h = (h ^ (unsigned char)p[i]) * 1099511628211ull;
+        return (size_t)(h ^ (h >> 29));
+    }
+    const Graph &g_;
+    std::vector<int32_t> slot_;
+};
+
+// would std::stoi(text) succeed?  (leading blanks, a sign, at least one digit,
+// value inside int)
+inline bool parses_as_int(const char *p, const char *end)
+{
+    while (p < end && (*p == ' ' || (*p >= '\t' && *p <= '\r'))) ++p;
+    bool neg = false;
+    if (p < end && (*p == '+' || *p == '-')) neg = *p++ == '-';
+    if (p >= end || *p < '0' || *p > '9') return false;
+    long long v = 0;
+    for (; p < end && *p >= '0' && *p <= '9'; ++p) {
+        v = v * 10 + (*p - '0');
+        if (v > 2147483648ll) return false;
+    }
+    return neg ? v <= 2147483648ll : v <= 2147483647ll;
+}
+
+inline bool read_gaf_paths(const std::string &file, const Graph &g, std::vector<int32_t> &off,
+                           std::vector<int32_t> &steps, std::string &err, unsigned n_threads = 0)
+{
+    off.assign(1, 0);
+    steps.clear();
+    int fd = open(file.c_str(), O_RDONLY);
+    if (fd < 0) {
+        err = "cannot open " + file;
+        return false;
+    }
+    struct stat st;
+    if (fstat(fd, &st) != 0) {
+        close(fd);
+        err = "cannot stat " + file;
+        return false;
+    }
+    const size_t size = (size_t)st.st_size;
+    if (size == 0) {
+        close(fd);
+        return true;
+    }
+    void *map = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (map == MAP_FAILED) {
+        err = "cannot map " + file;
+        return false;
+    }
+    const char *data = static_cast<const char *>(map);
+    if (n_threads == 0) n_threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    n_threads = (unsigned)std::min<size_t>(n_threads, size / (1 << 20) + 1);
+    // piece t = [cut[t], cut[t + 1]), every cut just after a newline
+    std::vector<size_t> cut(n_threads + 1, size);
+    cut[0] = 0;
+    for (unsigned t = 1; t < n_threads; ++t) {
+        size_t at = std::max(cut[t - 1], size / n_threads * t);
+        const void *nl = at < size ? memchr(data + at, '\n', size - at) : nullptr;
+        cut[t] = nl ? (size_t)(static_cast<const char *>(nl) - data) + 1 : size;
+    }
+    struct Piece {
+        std::vector<int32_t> lens, steps;
+        std::string err;
+    };
+    std::vector<Piece> pieces(n_threads);
+    const HeaderIndex index(g);
+    auto parse = [&](unsigned t) {
+        Piece &out = pieces[t];
+        const char *p = data + cut[t], *const end = data + cut[t + 1];
+        while (p < end) {
+            const char *nl = static_cast<const char *>(memchr(p, '\n', (size_t)(end - p)));
+            const char *line_end = nl ? nl : end;
+            const char *e = line_end;
+            if (e > p && e[-1] == '\r') --e;
+            // columns: starts of the first 12, end of the path column
+            const char *col[13];
+            int n_cols = 1;
+            col[0] = p;
+            for (const char *q = p; q < e && n_cols < 13; ++q)
+                if (*q == '\t') col[n_cols++] = q + 1;
+            if (n_cols < 12) {
+                out.err = "GAF record with fewer than 12 columns: " + std::string(p, e);
+                return;
+            }
+            if (n_cols == 12) col[12] = e + 1;
+            bool numeric = true;
+            for (int c : {1, 2, 3, 6, 7, 8, 9, 10, 11}) numeric &= parses_as_int(col[c], col[c + 1] - 1);
+            if (!numeric) {
+                out.err = "malformed GAF record: " + std::string(p, e);
+                return;
+            }
+            const char *q = col[5], *const path_end = col[6] - 1;
+            int32_t len = 0;
+            while (q < path_end) {       // src/alignments.cpp:75-94: marker, then the name
+                const char mark = *q++;
+                const char *name = q;
+                while (q < path_end && *q != '>' && *q != '<') ++q;
+                const uint32_t id = index.id_or_zero(name, (size_t)(q - name));
+                out.steps.push_back((int32_t)((id << 1) | (mark == '>' ? 0u : 1u)));
+                ++len;
+            }
+            out.lens.push_back(len);
+            p = nl ? nl + 1 : end;
+        }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < n_threads; ++t) pool.emplace_back(parse, t);
+    parse(0);
+    for (auto &th : pool) th.join();
+    munmap(map, size);
+    size_t n_rec = 0, n_steps = 0;
+    for (const Piece &pc : pieces) {
+        if (!pc.err.empty()) {
+            err = pc.err;
+            return false;
+        }
+        n_rec += pc.lens.size();
+        n_steps += pc.steps.size();
+    }
+    if (n_steps > (size_t)INT32_MAX) {
+        err = "more than 2^31 alignment steps";
+        return false;
+    }
+    off.reserve(n_rec + 1);
+    steps.reserve(n_steps);
+    for (const Piece &pc : pieces) {
+        for (int32_t len : pc.lens) off.push_back(off.back() + len);
+        steps.insert(steps.end(), pc.steps.begin(), pc.steps.end());
     }
     return true;
 }

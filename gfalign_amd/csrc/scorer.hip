@@ -27,11 +27,13 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "gfalign_scorer.h"
@@ -1733,6 +1735,51 @@ int gfal_scorer_create_ex(const int32_t *aln_off, const int32_t *aln_steps,
         int m = aln_off[k + 1] - aln_off[k];
         if (m > 0) by_len[(size_t)m].push_back((int32_t)k);
     }
+    {
+        // content order per length bucket: 64-bit key of the first four steps,
+        // the rest only on equal keys; buckets are sorted side by side
+        std::vector<int> lengths;
+        for (int m = 1; m <= max_len; ++m)
+            if (by_len[(size_t)m].size() > 1) lengths.push_back(m);
+        std::sort(lengths.begin(), lengths.end(), [&](int x, int y) {
+            return by_len[(size_t)x].size() > by_len[(size_t)y].size();
+        });
+        const uint16_t *ls = local_steps.data();
+        auto sort_bucket = [&](int m) {
+            struct Keyed {
+                uint64_t key;
+                int32_t idx;
+            };
+            std::vector<int32_t> &idx = by_len[(size_t)m];
+            std::vector<Keyed> keyed(idx.size());
+            for (size_t i = 0; i < idx.size(); ++i) {
+                const uint16_t *px = ls + aln_off[idx[i]];
+                uint64_t key = 0;
+                for (int t = 0; t < 4; ++t) key = (key << 16) | (t < m ? px[t] : 0u);
+                keyed[i] = Keyed{key, idx[i]};
+            }
+            std::sort(keyed.begin(), keyed.end(), [&](const Keyed &x, const Keyed &y) {
+                if (x.key != y.key) return x.key < y.key;
+                const uint16_t *px = ls + aln_off[x.idx], *py = ls + aln_off[y.idx];
+                for (int t = 4; t < m; ++t)
+                    if (px[t] != py[t]) return px[t] < py[t];
+                return x.idx < y.idx;
+            });
+            for (size_t i = 0; i < idx.size(); ++i) idx[i] = keyed[i].idx;
+        };
+        unsigned n_threads = std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency()));
+        if (const char *env = getenv("GFAL_CREATE_THREADS")) n_threads = (unsigned)std::max(1, atoi(env));
+        n_threads = (unsigned)std::min<size_t>(n_threads, std::max<size_t>(1, lengths.size()));
+        if (S < (1 << 16)) n_threads = 1;
+        std::atomic<size_t> next{0};
+        auto worker = [&]() {
+            for (size_t i = next++; i < lengths.size(); i = next++) sort_bucket(lengths[i]);
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < n_threads; ++t) pool.emplace_back(worker);
+        worker();
+        for (auto &t : pool) t.join();
+    }
     std::vector<uint16_t> item_steps;
     std::vector<uint32_t> item_base;
     std::vector<uint16_t> item_len;
@@ -1743,12 +1790,6 @@ int gfal_scorer_create_ex(const int32_t *aln_off, const int32_t *aln_steps,
         std::vector<int32_t> &idx = by_len[(size_t)m];
         if (idx.empty()) continue;
         const uint16_t *ls = local_steps.data();
-        std::sort(idx.begin(), idx.end(), [&](int32_t x, int32_t y) {
-            const uint16_t *px = ls + aln_off[x], *py = ls + aln_off[y];
-            for (int t = 0; t < m; ++t)
-                if (px[t] != py[t]) return px[t] < py[t];
-            return x < y;
-        });
         for (size_t at = 0; at < idx.size(); at += WAVE) {
             size_t cnt = std::min<size_t>(WAVE, idx.size() - at);
             size_t base = item_steps.size();

@@ -176,6 +176,19 @@ public:
         n_aln_ = a.size();
         if (n_aln_ == 0) return true;
         n_devices = (int)std::max<int64_t>(1, std::min<int64_t>(n_devices, n_aln_));
+        if (n_devices == 1) {      // one shard: the alignments as they are
+            members_.assign(1, {});
+            gfal_scorer *h = nullptr;
+            int rc = gfal_scorer_create_ex(a.off.data(), a.steps.data(), n_aln_, n_nodes,
+                                           first_device, universe.data(),
+                                           (int32_t)universe.size(), &h);
+            if (rc != GFAL_OK) {
+                fprintf(stderr, "Error: scorer: %s (%s)\n", gfal_strerror(rc), gfal_last_error());
+                return false;
+            }
+            shards_.push_back(h);
+            return true;
+        }
         // Which device owns which alignment: all copies of one alignment go to
         // one device (the scan kernel is fastest on runs of identical
         // alignments), groups are dealt heaviest-first in serpentine order so
@@ -272,6 +285,15 @@ public:
     {
         fw.assign((size_t)n_aln_, 0);
         rc.assign((size_t)n_aln_, 0);
+        if (shards_.size() == 1 && members_[0].empty()) {   // one shard, input order
+            int err = gfal_scorer_pair_scores(shards_[0], path.data(), (int32_t)path.size(),
+                                              fw.data(), rc.data());
+            if (err != GFAL_OK) {
+                fprintf(stderr, "Error: scorer: %s (%s)\n", gfal_strerror(err), gfal_last_error());
+                return false;
+            }
+            return true;
+        }
         for (size_t d = 0; d < shards_.size(); ++d) {
             const std::vector<int64_t> &mem = members_[d];
             std::vector<int32_t> f(mem.size()), r(mem.size());
