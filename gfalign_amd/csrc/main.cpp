@@ -502,9 +502,9 @@ int main(int argc, char **argv)
                     t_read - t_start, t_pack - t_read, t_open - t_pack, gfal::now_s() - t_open,
                     search.collect_seconds(), search.score_seconds());
         if (verbose_flag)
-            fprintf(stderr, "scored %llu candidate paths in %llu batches\n",
+            fprintf(stderr, "scored %llu candidate paths in %llu batches (%llu pairs took the exact DP)\n",
                     (unsigned long long)search.scored_paths(),
-                    (unsigned long long)search.batches());
+                    (unsigned long long)search.batches(), (unsigned long long)scorer.dp_pairs());
         return rc;
     }
     case 4: return run_filter(o, recs, totals);

@@ -969,40 +969,125 @@ __device__ __forceinline__ uint32_t *dp_row(uint32_t *row_scratch, int &stride)
     return row_scratch + blockIdx.x * DP_THREADS + threadIdx.x;
 }
 
-// The same fill with the row in registers: MC columns, fully unrolled.
-// b[] holds the (oriented) alignment, padded with STEP_INVALID; columns beyond
-// the lane's own m are computed and ignored (nothing flows from a column to
-// its left).  A lane with n == 0 does no work.
+// The same fill with the row in registers: MC columns, fully unrolled, one
+// table row per call.  b[] holds the (oriented) alignment, padded with
+// STEP_INVALID; columns beyond the lane's own m are computed and ignored
+// (nothing flows from a column to its left).  Column 0 is never written by
+// the reference: it is 0 in every row.
 template <int MC>
-__device__ __forceinline__ int traceback_score_regs(const uint16_t *__restrict__ astep,
-                                                    int n, const uint32_t (&b)[MC], int m)
+__device__ __forceinline__ void dp_row_regs(uint32_t ai, const uint32_t (&b)[MC], int m,
+                                            int (&dp)[MC + 1], int (&x)[MC + 1])
+{
+    int diag_dp = 0, diag_x = 0, left_dp = 0, left_x = 0;
+#pragma unroll
+    for (int j = 1; j <= MC; ++j) {
+        const int up_dp = dp[j], up_x = x[j];
+        const int d = diag_dp + ((ai == b[j - 1]) ? 0 : -1);
+        const int u = up_dp + ((j < m) ? -1 : 0);
+        const int l = left_dp - 1;
+        const int v = max(d, max(u, l));
+        const int xx = (v == d) ? diag_x : ((up_dp >= left_dp) ? up_x : left_x);
+        dp[j] = v;
+        x[j] = xx;
+        diag_dp = up_dp;
+        diag_x = up_x;
+        left_dp = v;
+        left_x = xx;
+    }
+}
+
+// Row skipping.  A row whose path step equals no step of B only subtracts: after
+// j such rows in a row the columns 1..j hold dp = -j with exit value 0, the last
+// column keeps its value, and further such rows change nothing (DESIGN.md
+// section 4, "steady state"; checked against the full fill in
+// tests/test_kernel_model.py).  So only the first m rows and the rows r..r+m
+// after every row r whose NODE occurs in B have to be computed -- a few dozen
+// of a 900-step path.  Doing more rows than that is always exact, so the window
+// is MC + 1 rows (a compile-time dilation) rather than m + 1.
+constexpr int ROW_WORDS = (GFAL_MAX_STEPS + 31) / 32;
+
+template <int MC>
+__device__ __forceinline__ unsigned long long dilate_rows(uint32_t bits)
+{
+    unsigned long long v = bits;     // span 1 -> MC + 1 by doubling
+    int span = 1;
+#pragma unroll
+    for (int step = 1; span < MC + 1; step <<= 1) {
+        const int by = min(step, MC + 1 - span);
+        v |= v << by;
+        span += by;
+    }
+    return v;
+}
+
+// Marks, in this lane's column of rowbits[][lane], the path positions whose node
+// occurs in the alignment: walks the occurrence chains of the m nodes (first[] /
+// next[] of the path image in HBM), all chains side by side.
+template <int MC>
+__device__ __forceinline__ void mark_match_rows(const uint16_t *__restrict__ img,
+                                                const ImageLayout &L,
+                                                const uint16_t *__restrict__ bp, int m,
+                                                uint32_t (*rowbits)[DP_THREADS], int lane)
+{
+    const uint16_t *first = img + L.first_at();
+    const uint32_t *next = reinterpret_cast<const uint32_t *>(img + L.next_at());
+    uint32_t cur[MC];
+#pragma unroll
+    for (int j = 0; j < MC; ++j)
+        cur[j] = j < m ? (uint32_t)first[(uint32_t)bp[j * WAVE] >> 1] : ENT_NONE;
+    while (true) {
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < MC; ++j) {
+            const bool on = cur[j] < ENT_FOUND;        // a position, not a terminal
+            const uint32_t pos = cur[j] & ENT_POS;
+            if (on) {
+                atomicOr(&rowbits[pos >> 5][lane], 1u << (pos & 31u));
+                cur[j] = next[pos];
+            }
+            any |= on;
+        }
+        if (!WAVE_ANY(any)) break;
+    }
+}
+
+// One orientation of one worklist entry per lane, rows in registers, only the
+// rows that can change the state.  `path_lds` holds the steps of the path most
+// lanes of the wave are on (`staged` lanes); the others read theirs from HBM.
+template <int MC>
+__device__ __forceinline__ int traceback_score_skip(const uint16_t *__restrict__ astep,
+                                                    const uint16_t *path_lds, bool staged, int n,
+                                                    const uint32_t (&b)[MC], int m,
+                                                    uint32_t (*rowbits)[DP_THREADS], int lane)
 {
     int dp[MC + 1], x[MC + 1];
 #pragma unroll
     for (int j = 0; j <= MC; ++j) {
-        dp[j] = (j <= n) ? -j : 0;
+        dp[j] = (j <= n) ? -j : 0;       // :500, row 0 reaches column n only
         x[j] = dp[j];
     }
-    for (int i = 1; i <= n; ++i) {
-        const uint32_t ai = astep[i - 1];
-        int diag_dp = dp[0], diag_x = x[0];
-        dp[0] = 0;
-        x[0] = 0;
-        int left_dp = 0, left_x = 0;
-#pragma unroll
-        for (int j = 1; j <= MC; ++j) {
-            const int up_dp = dp[j], up_x = x[j];
-            const int d = diag_dp + ((ai == b[j - 1]) ? 0 : -1);
-            const int u = up_dp + ((j < m) ? -1 : 0);
-            const int l = left_dp - 1;
-            const int v = max(d, max(u, l));
-            const int xx = (v == d) ? diag_x : ((up_dp >= left_dp) ? up_x : left_x);
-            dp[j] = v;
-            x[j] = xx;
-            diag_dp = up_dp;
-            diag_x = up_x;
-            left_dp = v;
-            left_x = xx;
+    int block = -1;                      // current 32-row block of the path
+    uint32_t todo = 0;                   // its rows still to compute
+    unsigned long long carry = (1ull << MC) - 1ull;   // rows 1..MC: the state is not steady yet
+    bool done = n == 0;
+    while (WAVE_ANY(!done)) {
+        if (todo == 0 && !done) {
+            ++block;
+            if (block * 32 >= n) {
+                done = true;
+            } else {
+                const unsigned long long rows = carry | dilate_rows<MC>(rowbits[block][lane]);
+                todo = (uint32_t)rows;
+                carry = rows >> 32;
+                const int left = n - block * 32;
+                if (left < 32) todo &= (1u << left) - 1u;
+            }
+        }
+        if (todo != 0) {
+            const int pos = block * 32 + __builtin_ctz(todo);
+            todo &= todo - 1u;
+            const uint32_t ai = staged ? (uint32_t)path_lds[pos] : (uint32_t)astep[pos];
+            dp_row_regs<MC>(ai, b, m, dp, x);
         }
     }
     int r = 0;
@@ -1011,13 +1096,14 @@ __device__ __forceinline__ int traceback_score_regs(const uint16_t *__restrict__
     return r;
 }
 
-// One worklist entry per lane: both orientations that were flagged, rows in
-// registers.  `second` lanes (both orientations flagged) run a second fill;
-// the others idle through it with n = 0.
+// One worklist entry per lane: the orientations that were flagged.  `second`
+// lanes (both flagged) run a second fill; the others idle through it with n = 0.
 template <int MC>
-__device__ __forceinline__ bool dp_decide_regs(const uint16_t *__restrict__ astep, int n,
+__device__ __forceinline__ bool dp_decide_regs(const uint16_t *__restrict__ astep,
+                                               const uint16_t *path_lds, bool staged, int n,
                                                const uint16_t *__restrict__ bp, int m,
-                                               bool has_fw, bool has_rc)
+                                               bool has_fw, bool has_rc,
+                                               uint32_t (*rowbits)[DP_THREADS], int lane)
 {
     uint32_t b[MC];
     // first orientation: fw if flagged, else rc
@@ -1029,9 +1115,9 @@ __device__ __forceinline__ bool dp_decide_regs(const uint16_t *__restrict__ aste
         if (j < m) v = (uint32_t)bp[src * WAVE] ^ (first_rc ? 1u : 0u);
         b[j] = v;
     }
-    bool good = traceback_score_regs<MC>(astep, n, b, m) == 0 && n > 0;
+    bool good = traceback_score_skip<MC>(astep, path_lds, staged, n, b, m, rowbits, lane) == 0 && n > 0;
     const bool second = has_fw && has_rc;
-    if (__any(second)) {
+    if (WAVE_ANY(second)) {
 #pragma unroll
         for (int j = 0; j < MC; ++j) {
             uint32_t v = STEP_INVALID;
@@ -1039,7 +1125,7 @@ __device__ __forceinline__ bool dp_decide_regs(const uint16_t *__restrict__ aste
             b[j] = v;
         }
         const int n2 = second ? n : 0;
-        good |= traceback_score_regs<MC>(astep, n2, b, m) == 0 && n2 > 0;
+        good |= traceback_score_skip<MC>(astep, path_lds, staged, n2, b, m, rowbits, lane) == 0 && n2 > 0;
     }
     return good;
 }
@@ -1100,13 +1186,33 @@ __global__ __launch_bounds__(256) void k_wl_scatter(
     if (*wl_count > wl_capacity) return;
     const uint32_t total = *wl_count;
     const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < total; w += stride) {
-        const unsigned long long ent = worklist[w];
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    // whole waves iterate together (the tail is padded with dead lanes)
+    for (uint32_t w0 = blockIdx.x * blockDim.x + (threadIdx.x & ~(WAVE - 1)); w0 < total;
+         w0 += stride) {
+        const uint32_t w = w0 + lane;
+        const bool live = w < total;
+        const unsigned long long ent = live ? worklist[w] : 0ull;
         const uint32_t p = (uint32_t)(ent >> 32) & WL_PATH_MASK;
         const uint32_t it = (uint32_t)ent >> 6;
-        const uint32_t bin = (uint32_t)length_class((int)items.len[it]) * n_paths + p;
-        const uint32_t at = offsets[bin] + atomicAdd(&cursor[bin], 1u);
-        sorted[at] = ent;
+        const uint32_t bin =
+            live ? (uint32_t)length_class((int)items.len[it]) * n_paths + p : 0xFFFFFFFFu;
+        // the scan appends runs of one (path, item): most of a wave lands in one
+        // bin, so one atomic per distinct bin instead of one per entry
+        lanemask todo = WAVE_MASK(live);
+        uint32_t at = 0;
+        while (todo) {
+            const int leader = __builtin_ctzll(todo);
+            const uint32_t lead_bin = (uint32_t)__builtin_amdgcn_readlane((int)bin, leader);
+            const lanemask same = WAVE_MASK(bin == lead_bin) & todo;
+            uint32_t base = 0;
+            if ((int)lane == leader) base = atomicAdd(&cursor[lead_bin], (uint32_t)__builtin_popcountll(same));
+            base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+            if (bin == lead_bin && live)
+                at = offsets[bin] + base + (uint32_t)__builtin_popcountll(same & ((1ull << lane) - 1ull));
+            todo &= ~same;
+        }
+        if (live) sorted[at] = ent;
     }
 }
 
@@ -1160,17 +1266,38 @@ __device__ __forceinline__ DpEntry load_entry(const DpArgs &a, uint32_t w, bool 
 template <int MC, int CLS>
 __global__ __launch_bounds__(DP_THREADS) void k_dp_regs(DpArgs a)
 {
+    __shared__ uint32_t rowbits[ROW_WORDS][DP_THREADS];   // per lane: rows whose node is in B
+    __shared__ uint16_t path_lds[GFAL_MAX_STEPS + 8];
     if (*a.wl_count > a.wl_capacity) return;     // overflow: see k_wl_scatter
     const uint32_t total = *a.wl_count;
     if (total <= a.sys_limit) return;            // short list: k_dp_sys does it
     uint32_t lo, hi;
     class_range(a.class_lo, CLS, total, lo, hi);
     const uint32_t n_threads = gridDim.x * DP_THREADS;
+    const int lane = threadIdx.x;
     for (uint32_t w0 = lo + blockIdx.x * DP_THREADS; w0 < hi; w0 += n_threads) {
         const uint32_t w = w0 + threadIdx.x;
         const bool live = w < hi;
         const DpEntry e = load_entry(a, w, live);
-        bool good = dp_decide_regs<MC>(e.astep, e.n, e.bp, e.m, e.has_fw, e.has_rc);
+        // the list is sorted by path: stage the first lane's path, nearly every
+        // lane of the wave is on it
+        const uint32_t lead_p = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.p);
+        const int lead_n = __builtin_amdgcn_readfirstlane(e.n);
+        __syncthreads();
+        {
+            const uint16_t *lead_steps = a.images + (size_t)lead_p * a.L.total + a.L.step_at();
+            for (int i = lane; i < lead_n; i += DP_THREADS) path_lds[i] = lead_steps[i];
+        }
+        int n_max = e.n;
+#pragma unroll
+        for (int o = 1; o < WAVE; o <<= 1) n_max = max(n_max, __shfl_xor(n_max, o, WAVE));
+        const int n_words = (__builtin_amdgcn_readfirstlane(n_max) + 31) >> 5;
+        for (int k = 0; k < n_words; ++k) rowbits[k][lane] = 0;
+        __syncthreads();
+        const bool staged = e.p == lead_p;
+        mark_match_rows<MC>(a.images + (size_t)e.p * a.L.total, a.L, e.bp, e.m, rowbits, lane);
+        bool good = dp_decide_regs<MC>(e.astep, path_lds, staged, e.n, e.bp, e.m, e.has_fw,
+                                       e.has_rc, rowbits, lane);
 #if defined(GFAL_ABLATE) && GFAL_ABLATE == 3
         good = false;
 #endif

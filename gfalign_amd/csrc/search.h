@@ -276,9 +276,12 @@ public:
                 bad[k] += pb[d][k];
                 good[k] += pg[d][k];
             }
+            gfal_info info;
+            if (gfal_scorer_get_info(shards_[d], &info) == GFAL_OK) dp_pairs_ += (uint64_t)info.dp_pairs;
         }
         return true;
     }
+    uint64_t dp_pairs() const { return dp_pairs_; }   // pairs that needed the exact DP so far
     // fw / rc traceback scores of one path against every alignment, in input order
     bool pair_scores(const std::vector<int32_t> &path, std::vector<int32_t> &fw,
                      std::vector<int32_t> &rc)
@@ -317,6 +320,7 @@ private:
     std::vector<gfal_scorer *> shards_;
     std::vector<std::vector<int64_t>> members_;   // per shard: alignment indices, ascending
     int64_t n_aln_ = 0;
+    uint64_t dp_pairs_ = 0;
 };
 
 struct SearchOptions {
@@ -340,7 +344,14 @@ struct SearchOptions {
 class Search {
 public:
     Search(const Graph &g, PathScorer &scorer, const SearchOptions &opt, std::ostream &out)
-        : g_(g), scorer_(scorer), opt_(opt), out_(out) {}
+        : g_(g), scorer_(scorer), opt_(opt), out_(out)
+    {
+        if (const char *f = getenv("GFALIGN_DUMP_BATCHES")) dump_ = fopen(f, "wb");
+    }
+    ~Search()
+    {
+        if (dump_) fclose(dump_);
+    }
 
     int run()
     {
@@ -499,6 +510,12 @@ private:
             level.swap(next);
         }
         std::vector<uint32_t> bad, good;
+        if (dump_) {   // GFALIGN_DUMP_BATCHES: the candidate batches, for benchmarks
+            const int32_t head[2] = {(int32_t)n_paths, (int32_t)steps.size()};
+            fwrite(head, sizeof(int32_t), 2, dump_);
+            fwrite(off.data(), sizeof(int32_t), off.size(), dump_);
+            fwrite(steps.data(), sizeof(int32_t), steps.size(), dump_);
+        }
         const double t1 = now_s();
         t_collect_ += t1 - t0;
         if (!scorer_.score(off, steps, true, bad, good)) return false;   // :162
@@ -527,6 +544,7 @@ private:
     std::map<Key, std::unique_ptr<Node>> queue_;
     uint64_t seq_ = 0, scored_ = 0, batches_ = 0;
     double t_collect_ = 0, t_score_ = 0;
+    FILE *dump_ = nullptr;
 };
 
 }  // namespace gfal
