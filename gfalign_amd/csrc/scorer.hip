@@ -1267,10 +1267,13 @@ template <int MC, int CLS>
 __global__ __launch_bounds__(DP_THREADS) void k_dp_regs(DpArgs a)
 {
     __shared__ uint32_t rowbits[ROW_WORDS][DP_THREADS];   // per lane: rows whose node is in B
-    __shared__ uint16_t path_lds[GFAL_MAX_STEPS + 8];
+    constexpr int STAGED_PATHS = 4;
+    __shared__ uint16_t path_lds[STAGED_PATHS][GFAL_MAX_STEPS + 8];
     if (*a.wl_count > a.wl_capacity) return;     // overflow: see k_wl_scatter
     const uint32_t total = *a.wl_count;
-    if (total <= a.sys_limit) return;            // short list: k_dp_sys does it
+    // short list: from 16 columns up the wavefront kernels have the lower latency
+    // (with few columns the skipped rows count for more, see k_dp_sys)
+    if (CLS >= 2 && total <= a.sys_limit) return;
     uint32_t lo, hi;
     class_range(a.class_lo, CLS, total, lo, hi);
     const uint32_t n_threads = gridDim.x * DP_THREADS;
@@ -1279,14 +1282,23 @@ __global__ __launch_bounds__(DP_THREADS) void k_dp_regs(DpArgs a)
         const uint32_t w = w0 + threadIdx.x;
         const bool live = w < hi;
         const DpEntry e = load_entry(a, w, live);
-        // the list is sorted by path: stage the first lane's path, nearly every
-        // lane of the wave is on it
-        const uint32_t lead_p = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.p);
-        const int lead_n = __builtin_amdgcn_readfirstlane(e.n);
+        // the list is sorted by path: a wave is on one path, or on a few where
+        // the paths change; the first STAGED_PATHS of them go to LDS (a lane on
+        // a later one reads its steps from HBM, one exposed latency per row)
+        const uint32_t prev_p = (uint32_t)__shfl_up((int)e.p, 1, WAVE);
+        const lanemask starts = WAVE_MASK(live && (lane == 0 || e.p != prev_p));
+        const int slot = __builtin_popcountll(starts & ((2ull << lane) - 1ull)) - 1;
         __syncthreads();
         {
-            const uint16_t *lead_steps = a.images + (size_t)lead_p * a.L.total + a.L.step_at();
-            for (int i = lane; i < lead_n; i += DP_THREADS) path_lds[i] = lead_steps[i];
+            lanemask left = starts;
+            for (int k = 0; k < STAGED_PATHS && left; ++k) {
+                const int leader = __builtin_ctzll(left);
+                left &= left - 1;
+                const uint32_t p_k = (uint32_t)__builtin_amdgcn_readlane((int)e.p, leader);
+                const int n_k = __builtin_amdgcn_readlane(e.n, leader);
+                const uint16_t *src = a.images + (size_t)p_k * a.L.total + a.L.step_at();
+                for (int i = lane; i < n_k; i += DP_THREADS) path_lds[k][i] = src[i];
+            }
         }
         int n_max = e.n;
 #pragma unroll
@@ -1294,9 +1306,10 @@ __global__ __launch_bounds__(DP_THREADS) void k_dp_regs(DpArgs a)
         const int n_words = (__builtin_amdgcn_readfirstlane(n_max) + 31) >> 5;
         for (int k = 0; k < n_words; ++k) rowbits[k][lane] = 0;
         __syncthreads();
-        const bool staged = e.p == lead_p;
+        const bool staged = live && slot < STAGED_PATHS;
+        const uint16_t *my_path = path_lds[staged ? slot : 0];
         mark_match_rows<MC>(a.images + (size_t)e.p * a.L.total, a.L, e.bp, e.m, rowbits, lane);
-        bool good = dp_decide_regs<MC>(e.astep, path_lds, staged, e.n, e.bp, e.m, e.has_fw,
+        bool good = dp_decide_regs<MC>(e.astep, my_path, staged, e.n, e.bp, e.m, e.has_fw,
                                        e.has_rc, rowbits, lane);
 #if defined(GFAL_ABLATE) && GFAL_ABLATE == 3
         good = false;
@@ -1356,7 +1369,7 @@ __device__ __forceinline__ void sys_step(int s, int j, int n, uint32_t b, int up
 template <int MC>
 __global__ __launch_bounds__(DP_THREADS) void k_dp_sys(DpArgs a)
 {
-    static_assert(MC == 4 || MC == 8 || MC == 16 || MC == 64, "group inside a DPP row, or the wave");
+    static_assert(MC == 16 || MC == 64, "group = DPP row, or the wave");
     constexpr int G = WAVE / MC;                          // lane groups (fills) per wave
     // MC < 64: an entry takes two neighbouring groups, one per orientation;
     // MC = 64: one entry per wave, the orientations one after the other
@@ -1366,9 +1379,10 @@ __global__ __launch_bounds__(DP_THREADS) void k_dp_sys(DpArgs a)
     if (*a.wl_count > a.wl_capacity) return;              // overflow: see k_wl_scatter
     const uint32_t total = *a.wl_count;
     if (total > a.sys_limit) return;                      // long list: k_dp_regs / k_dp_long
-    // MC = 4, 8, 16: classes 0, 1, 2; MC = 64: class 3 and the entries of the
-    // last class that fit (k_dp_long skips those on a short list)
-    constexpr int CLS = MC == 4 ? 0 : MC == 8 ? 1 : MC == 16 ? 2 : 3;
+    // MC = 16: class 2; MC = 64: class 3 and the entries of the last class that
+    // fit (k_dp_long skips those on a short list); classes 0 and 1 always take
+    // k_dp_regs, whose row skipping beats the wavefront for few columns
+    constexpr int CLS = MC == 16 ? 2 : 3;
     const uint32_t lo = min(a.class_lo[CLS], total);
     const uint32_t hi = MC == 64 ? total : min(a.class_lo[CLS + 1], total);
     const int lane = threadIdx.x;
@@ -2191,13 +2205,10 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
         };
         // every kernel of both families is launched; the list length (known on
         // the device only) decides which family returns at once
-        hipLaunchKernelGGL(k_dp_sys<4>, dim3(DP_SYS_BLOCKS), dim3(DP_THREADS), 0, st, d);
         hipLaunchKernelGGL((k_dp_regs<4, 0>), dim3(DP_REG_BLOCKS), dim3(DP_THREADS), 0, st, d);
-        if (s->max_aln_len > 4) {
-            hipStream_t s0 = side(0);
-            hipLaunchKernelGGL(k_dp_sys<8>, dim3(DP_SYS_BLOCKS), dim3(DP_THREADS), 0, s0, d);
-            hipLaunchKernelGGL((k_dp_regs<8, 1>), dim3(DP_REG_BLOCKS), dim3(DP_THREADS), 0, s0, d);
-        }
+        if (s->max_aln_len > 4)
+            hipLaunchKernelGGL((k_dp_regs<8, 1>), dim3(DP_REG_BLOCKS), dim3(DP_THREADS), 0,
+                               side(0), d);
         if (s->max_aln_len > 8) {
             hipStream_t s1 = side(1);
             hipLaunchKernelGGL(k_dp_sys<16>, dim3(DP_SYS_BLOCKS), dim3(DP_THREADS), 0, s1, d);

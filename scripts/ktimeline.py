@@ -4,7 +4,7 @@ import csv, glob, os, sys
 files = sorted(glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)
 rows = list(csv.DictReader(open(files[-1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-last = max(i for i, r in enumerate(rows) if "k_len_hist" in r["Kernel_Name"])
+last = max(i for i, r in enumerate(rows) if ("k_len_sort_block" in r["Kernel_Name"] or "k_len_hist" in r["Kernel_Name"]))
 t0 = int(rows[last]["Start_Timestamp"])
 for r in rows[last:]:
     name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:28]
