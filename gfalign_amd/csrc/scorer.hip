@@ -1026,26 +1026,32 @@ __device__ __forceinline__ unsigned long long dilate_rows(uint32_t bits)
 template <int MC>
 __device__ __forceinline__ void mark_match_rows(const uint16_t *__restrict__ img,
                                                 const ImageLayout &L,
-                                                const uint16_t *__restrict__ bp, int m,
+                                                const uint32_t (&steps)[MC], int m,
                                                 uint32_t (*rowbits)[DP_THREADS], int lane)
 {
     const uint16_t *first = img + L.first_at();
     const uint32_t *next = reinterpret_cast<const uint32_t *>(img + L.next_at());
+    // every load below is unconditional (terminal codes index next[1022..1023],
+    // which hold ENT_NONE; steps[] beyond m repeat a real step): MC independent
+    // loads in flight per round, not MC exposed latencies
     uint32_t cur[MC];
 #pragma unroll
-    for (int j = 0; j < MC; ++j)
-        cur[j] = j < m ? (uint32_t)first[(uint32_t)bp[j * WAVE] >> 1] : ENT_NONE;
+    for (int j = 0; j < MC; ++j) {
+        const uint32_t head = first[j < m ? steps[j] >> 1 : 0u];   // index 0: always inside
+        cur[j] = j < m ? head : ENT_NONE;
+    }
     while (true) {
+        uint32_t nx[MC];
+#pragma unroll
+        for (int j = 0; j < MC; ++j) nx[j] = next[cur[j] & ENT_POS];
         bool any = false;
 #pragma unroll
         for (int j = 0; j < MC; ++j) {
             const bool on = cur[j] < ENT_FOUND;        // a position, not a terminal
             const uint32_t pos = cur[j] & ENT_POS;
-            if (on) {
-                atomicOr(&rowbits[pos >> 5][lane], 1u << (pos & 31u));
-                cur[j] = next[pos];
-            }
+            if (on) atomicOr(&rowbits[pos >> 5][lane], 1u << (pos & 31u));
             any |= on;
+            cur[j] = on ? nx[j] : ENT_NONE;
         }
         if (!WAVE_ANY(any)) break;
     }
@@ -1098,11 +1104,12 @@ __device__ __forceinline__ int traceback_score_skip(const uint16_t *__restrict__
 
 // One worklist entry per lane: the orientations that were flagged.  `second`
 // lanes (both flagged) run a second fill; the others idle through it with n = 0.
+// fwd[j] = B[min(j, m-1)], rev[j] = B[max(m-1-j, 0)], loaded by the caller.
 template <int MC>
 __device__ __forceinline__ bool dp_decide_regs(const uint16_t *__restrict__ astep,
                                                const uint16_t *path_lds, bool staged, int n,
-                                               const uint16_t *__restrict__ bp, int m,
-                                               bool has_fw, bool has_rc,
+                                               const uint32_t (&fwd)[MC], const uint32_t (&rev)[MC],
+                                               int m, bool has_fw, bool has_rc,
                                                uint32_t (*rowbits)[DP_THREADS], int lane)
 {
     uint32_t b[MC];
@@ -1110,20 +1117,14 @@ __device__ __forceinline__ bool dp_decide_regs(const uint16_t *__restrict__ aste
     const bool first_rc = !has_fw;
 #pragma unroll
     for (int j = 0; j < MC; ++j) {
-        const int src = first_rc ? (m - 1 - j) : j;
-        uint32_t v = STEP_INVALID;
-        if (j < m) v = (uint32_t)bp[src * WAVE] ^ (first_rc ? 1u : 0u);
-        b[j] = v;
+        const uint32_t v = first_rc ? (rev[j] ^ 1u) : fwd[j];
+        b[j] = j < m ? v : STEP_INVALID;
     }
     bool good = traceback_score_skip<MC>(astep, path_lds, staged, n, b, m, rowbits, lane) == 0 && n > 0;
     const bool second = has_fw && has_rc;
     if (WAVE_ANY(second)) {
 #pragma unroll
-        for (int j = 0; j < MC; ++j) {
-            uint32_t v = STEP_INVALID;
-            if (j < m) v = (uint32_t)bp[(m - 1 - j) * WAVE] ^ 1u;
-            b[j] = v;
-        }
+        for (int j = 0; j < MC; ++j) b[j] = j < m ? (rev[j] ^ 1u) : STEP_INVALID;
         const int n2 = second ? n : 0;
         good |= traceback_score_skip<MC>(astep, path_lds, staged, n2, b, m, rowbits, lane) == 0 && n2 > 0;
     }
@@ -1262,6 +1263,33 @@ __device__ __forceinline__ DpEntry load_entry(const DpArgs &a, uint32_t w, bool 
     return e;
 }
 
+// Adds a wave's decisions to the per-path counters: two atomics per distinct
+// path of the wave (runs of equal p; the list is sorted by path), not one per
+// lane -- all resident waves work on the same few paths at a time, and per-lane
+// atomics on those few words were 75 % of the DP phase.
+__device__ __forceinline__ void add_results_by_path(const DpArgs &a, uint32_t p, bool live,
+                                                    bool good, int lane)
+{
+    const uint32_t prev_p = (uint32_t)__shfl_up((int)p, 1, WAVE);
+    const lanemask live_mask = WAVE_MASK(live), good_mask = WAVE_MASK(good && live);
+    // a run starts at a live lane whose left neighbour is dead or on another path
+    const lanemask starts =
+        WAVE_MASK(live && (lane == 0 || p != prev_p || !((live_mask >> (lane - 1)) & 1ull)));
+    lanemask left = starts;
+    while (left) {
+        const int leader = __builtin_ctzll(left);
+        left &= left - 1;
+        const lanemask upto = left ? ((1ull << __builtin_ctzll(left)) - 1ull) : ~0ull;
+        const lanemask mine = upto & ~((1ull << leader) - 1ull) & live_mask;
+        const uint32_t n_good = (uint32_t)__builtin_popcountll(mine & good_mask);
+        const uint32_t n_bad = (uint32_t)__builtin_popcountll(mine) - n_good;
+        if (lane == leader) {
+            if (n_good) atomicAdd(&a.counts[a.n_paths + p], n_good);
+            if (n_bad) atomicAdd(&a.counts[p], n_bad);
+        }
+    }
+}
+
 // Length classes 0..3: rows in MC registers.
 template <int MC, int CLS>
 __global__ __launch_bounds__(DP_THREADS) void k_dp_regs(DpArgs a)
@@ -1297,8 +1325,24 @@ __global__ __launch_bounds__(DP_THREADS) void k_dp_regs(DpArgs a)
                 const uint32_t p_k = (uint32_t)__builtin_amdgcn_readlane((int)e.p, leader);
                 const int n_k = __builtin_amdgcn_readlane(e.n, leader);
                 const uint16_t *src = a.images + (size_t)p_k * a.L.total + a.L.step_at();
-                for (int i = lane; i < n_k; i += DP_THREADS) path_lds[k][i] = src[i];
+                // all loads of a path in flight before the first store
+                constexpr int LOADS = (GFAL_MAX_STEPS + DP_THREADS - 1) / DP_THREADS;
+                uint16_t t[LOADS];
+#pragma unroll
+                for (int q = 0; q < LOADS; ++q)
+                    t[q] = src[min(lane + q * DP_THREADS, max(n_k - 1, 0))];
+#pragma unroll
+                for (int q = 0; q < LOADS; ++q)
+                    if (lane + q * DP_THREADS < n_k) path_lds[k][lane + q * DP_THREADS] = t[q];
             }
+        }
+        // the alignment, forward and reversed, with unconditional loads (2 * MC in
+        // flight; a load per `if (j < m)` would expose 2 * MC latencies)
+        uint32_t fwd[MC], rev[MC];
+#pragma unroll
+        for (int j = 0; j < MC; ++j) {
+            fwd[j] = (uint32_t)e.bp[max(min(j, e.m - 1), 0) * WAVE];
+            rev[j] = (uint32_t)e.bp[max(e.m - 1 - j, 0) * WAVE];
         }
         int n_max = e.n;
 #pragma unroll
@@ -1308,13 +1352,13 @@ __global__ __launch_bounds__(DP_THREADS) void k_dp_regs(DpArgs a)
         __syncthreads();
         const bool staged = live && slot < STAGED_PATHS;
         const uint16_t *my_path = path_lds[staged ? slot : 0];
-        mark_match_rows<MC>(a.images + (size_t)e.p * a.L.total, a.L, e.bp, e.m, rowbits, lane);
-        bool good = dp_decide_regs<MC>(e.astep, my_path, staged, e.n, e.bp, e.m, e.has_fw,
+        mark_match_rows<MC>(a.images + (size_t)e.p * a.L.total, a.L, fwd, e.m, rowbits, lane);
+        bool good = dp_decide_regs<MC>(e.astep, my_path, staged, e.n, fwd, rev, e.m, e.has_fw,
                                        e.has_rc, rowbits, lane);
 #if defined(GFAL_ABLATE) && GFAL_ABLATE == 3
         good = false;
 #endif
-        if (live) atomicAdd(&a.counts[(good ? a.n_paths : 0) + e.p], 1u);
+        add_results_by_path(a, e.p, live, good, lane);
     }
 }
 
@@ -1462,7 +1506,8 @@ __global__ __launch_bounds__(DP_THREADS) void k_dp_sys(DpArgs a)
         constexpr int SPAN = MC == 64 ? 64 : 2 * MC;
         const lanemask gm = WAVE_MASK(good);
         const lanemask mine = (gm >> (lane / SPAN * SPAN)) & (SPAN == 64 ? ~0ull : ((1ull << SPAN) - 1ull));
-        if (live && lane % SPAN == 0) atomicAdd(&a.counts[(mine != 0 ? a.n_paths : 0) + e.p], 1u);
+        // one result per entry, carried by the first lane of its span
+        add_results_by_path(a, e.p, live && lane % SPAN == 0, mine != 0, lane);
     }
 }
 
@@ -1491,7 +1536,7 @@ __global__ __launch_bounds__(DP_THREADS) void k_dp_long(DpArgs a)
         B.flip = 1u;
         const int rc = traceback_score(A, B, row, stride);
         const bool good = fw == 0 || rc == 0;
-        if (mine) atomicAdd(&a.counts[(good ? a.n_paths : 0) + e.p], 1u);
+        add_results_by_path(a, e.p, mine, good, (int)threadIdx.x);
     }
 }
 

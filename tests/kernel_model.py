@@ -36,6 +36,51 @@ def traceback_score(A, B):
     return dp[m] - ex[m]
 
 
+def traceback_score_skip(A, B, window=None):
+    """scorer.hip traceback_score_skip(): the same fill, computing only the
+    first `window` rows and the rows r .. r + window after every row r whose
+    path step has a node that occurs in B (window = m by default; the kernel
+    uses its column count MC >= m, any larger window is exact too).  All other
+    rows leave the state unchanged: after j rows without a matching step the
+    columns 1..j hold dp = -j with exit value 0 and the last column keeps its
+    value.  Returns (score, rows computed).  Needs m <= n (the kernels only
+    run the DP then)."""
+    n, m = len(A), len(B)
+    assert m <= n
+    w = m if window is None else window
+    assert w >= m
+    nodes = {b >> 1 for b in B}
+    dp = [-j for j in range(m + 1)]
+    ex = list(dp)
+    remaining, rows = w, 0
+    for i in range(1, n + 1):
+        if A[i - 1] is not None and (A[i - 1] >> 1) in nodes:
+            remaining = w + 1
+        if remaining == 0:
+            continue
+        remaining -= 1
+        rows += 1
+        diag_dp, diag_x = 0, 0          # column 0 is 0 in every row
+        left_dp, left_x = 0, 0
+        for j in range(1, m + 1):
+            up_dp, up_x = dp[j], ex[j]
+            sub = 0 if A[i - 1] == B[j - 1] else -1
+            d = diag_dp + sub
+            u = up_dp + (-1 if j < m else 0)
+            l = left_dp - 1
+            v = max(d, u, l)
+            if v == d:
+                x = diag_x
+            elif up_dp >= left_dp:
+                x = up_x
+            else:
+                x = left_x
+            dp[j], ex[j] = v, x
+            diag_dp, diag_x = up_dp, up_x
+            left_dp, left_x = v, x
+    return dp[m] - ex[m], rows
+
+
 def has_overhang(A, B):
     m = len(B)
     for ln in range(1, min(m - 1, len(A)) + 1):
