@@ -423,6 +423,9 @@ __device__ __forceinline__ void push_pairs(const ScanArgs &a, bool fw, bool rc, 
     const bool want = fw || rc;
     unsigned long long m = __builtin_amdgcn_ballot_w64(want);
     if (m == 0) return;
+#if defined(GFAL_ABLATE) && GFAL_ABLATE == 5      // timing probe: what do the appends cost?
+    return;
+#endif
     uint32_t base = 0;
     int leader = __ffsll((long long)m) - 1;
     if (lane == leader) {
@@ -1198,21 +1201,23 @@ __global__ __launch_bounds__(256) void k_wl_scatter(
         const uint32_t it = (uint32_t)ent >> 6;
         const uint32_t bin =
             live ? (uint32_t)length_class((int)items.len[it]) * n_paths + p : 0xFFFFFFFFu;
-        // the scan appends runs of one (path, item): most of a wave lands in one
-        // bin, so one atomic per distinct bin instead of one per entry
-        lanemask todo = WAVE_MASK(live);
-        uint32_t at = 0;
-        while (todo) {
-            const int leader = __builtin_ctzll(todo);
-            const uint32_t lead_bin = (uint32_t)__builtin_amdgcn_readlane((int)bin, leader);
-            const lanemask same = WAVE_MASK(bin == lead_bin) & todo;
-            uint32_t base = 0;
-            if ((int)lane == leader) base = atomicAdd(&cursor[lead_bin], (uint32_t)__builtin_popcountll(same));
-            base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
-            if (bin == lead_bin && live)
-                at = offsets[bin] + base + (uint32_t)__builtin_popcountll(same & ((1ull << lane) - 1ull));
-            todo &= ~same;
-        }
+        // the scan appends runs of one (path, item): one atomic per run of equal
+        // bins (all of a wave's runs in flight together), not one per entry --
+        // on a search batch a whole wave often lands in a single bin
+        const uint32_t prev_bin = (uint32_t)__shfl_up((int)bin, 1, WAVE);
+        const lanemask heads = WAVE_MASK(live && (lane == 0 || bin != prev_bin));
+        const lanemask live_mask = WAVE_MASK(live);
+        const lanemask upto_me = heads & ((2ull << lane) - 1ull);
+        const int head = 63 - __builtin_clzll(upto_me | 1ull);          // my run's first lane
+        const lanemask after = heads & ~((2ull << head) - 1ull);         // heads of later runs
+        const int run_end = after ? __builtin_ctzll(after) : 64;         // one past my run
+        const lanemask run = (run_end == 64 ? ~0ull : ((1ull << run_end) - 1ull)) &
+                             ~((1ull << head) - 1ull) & live_mask;
+        uint32_t base = 0;
+        if (live && (int)lane == head)
+            base = atomicAdd(&cursor[bin], (uint32_t)__builtin_popcountll(run));
+        base = (uint32_t)__shfl((int)base, head, WAVE);
+        const uint32_t at = live ? offsets[bin] + base + (uint32_t)(lane - head) : 0u;
         if (live) sorted[at] = ent;
     }
 }

@@ -13,5 +13,12 @@ rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_V
 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d gpurun_out/prof_${tag}_sq2 -- $B --steps 3 --warmup 1 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/prof_${tag}_grbm -- $B --steps 3 --warmup 1 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof_${tag}_calib -- ./tools/fetch_calib > gpurun_out/prof_${tag}_calib.log 2>&1
+{
+  echo "## search-sized batches (scripts/small_batch_probe.py config3)"; python3 scripts/small_batch_probe.py config3 8,32,128,512,2048
+  echo "## candidate batches of the search itself (scripts/search_batch.py config3 10000 20000 <skip>)"
+  python3 scripts/search_batch.py config3 10000 20000 0; python3 scripts/search_batch.py config3 10000 20000 50000
+  echo "## gfalign search end to end (scripts/e2e_search.py config3 20000 32,128)"; python3 scripts/e2e_search.py config3 20000 32,128
+  echo "## one rank's share of 8 (scripts/shard_probe.py 8 8192)"; python3 scripts/shard_probe.py 8 8192 2>&1 | grep shard
+} > gpurun_out/workloads_${tag}.txt 2>&1
 python3 bench.py --steps 20 --warmup 3 > gpurun_out/bench_${tag}_full.json 2> gpurun_out/bench_${tag}_full.err
 tail -c 600 gpurun_out/bench_${tag}_full.json

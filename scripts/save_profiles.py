@@ -2,7 +2,8 @@
 import collections, csv, glob, json, os, shutil, sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-KEYS = ("k_scan", "k_dp_regs<8", "k_dp_regs<16", "k_dp_regs<32", "k_dp_long", "k_prep",
+KEYS = ("k_scan", "k_dp_regs<4", "k_dp_regs<8", "k_dp_regs<16", "k_dp_regs<32", "k_dp_long", "k_dp_sys",
+        "k_len_sort_block", "k_prep",
         "k_wl_scatter", "k_wl_offsets", "read_u16", "read_b128")
 
 
@@ -51,6 +52,8 @@ traffic = {
               "this is an upper bound on HBM bytes",
     "source": "profiles/%s_pmc_config3.json" % tag}
 json.dump(traffic, open("profiles/traffic_config3.json", "w"), indent=1)
+if os.path.exists("gpurun_out/workloads_%s.txt" % tag):
+    shutil.copy("gpurun_out/workloads_%s.txt" % tag, "profiles/%s_workloads.txt" % tag)
 try:
     line = open("gpurun_out/bench_%s_full.json" % tag).read().strip().splitlines()[-1]
     json.loads(line)
