@@ -99,8 +99,10 @@ def main():
 
     t = synth.make(args.workload)
     t.name = args.workload
-    aoff, ast = shard.take_shard(t.aln_off, t.aln_steps, rank, world)
-    sc = Scorer(aoff, ast, t.V, device=local_rank)
+    # every rank hands the scorer the whole set and keeps its share of the
+    # scorer's own sorted order (gfal_scorer_create_sharded): the shards partition
+    # the set, balance by construction and do 1/world of the unsharded work each
+    sc = Scorer(t.aln_off, t.aln_steps, t.V, device=local_rank, shard=(rank, world))
 
     P = t.P
     total_steps = int(t.path_off[-1])
@@ -155,7 +157,7 @@ def main():
         # dominant kernel: k_scan.  Algorithmic bytes of one launch on this rank
         # (SURVEY.md 8(d)): sum over candidates of 4 S + 4 (N+1) + 4 n + 12 with
         # this rank's S and N.
-        S_r, N_r = int(aoff[-1]), len(aoff) - 1
+        S_r, N_r = int(info["n_steps"]), int(info["n_aln"])
         alg_bytes = P * (4 * S_r + 4 * (N_r + 1) + 12) + 4 * total_steps
         scan_s = info["scan_ms"] * 1e-3
         achieved = alg_bytes / scan_s / 1e9 if scan_s > 0 else None

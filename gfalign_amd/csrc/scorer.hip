@@ -1239,7 +1239,7 @@ struct DpArgs {
     const uint32_t *class_lo;   // [N_CLASSES + 1] ranges of the sorted list
     const uint32_t *wl_count;
     uint32_t wl_capacity;
-    uint32_t sys_limit;         // worklists up to this size take the k_dp_sys kernels
+    uint32_t sys_limit;         // see wavefront_class()
     uint32_t *row_scratch;
     uint32_t *counts;
 };
@@ -1266,6 +1266,18 @@ __device__ __forceinline__ DpEntry load_entry(const DpArgs &a, uint32_t w, bool 
     e.has_fw = (ent & WL_FW) != 0;
     e.has_rc = (ent & WL_RC) != 0;
     return e;
+}
+
+// Which kernel family runs length class 2 (up to 16 columns) or the classes
+// from 3 up (17 and more): the wavefront kernels (k_dp_sys) while the class holds
+// few entries -- then the latency of one fill decides, and a column per lane has
+// the shorter one -- the one-pair-per-lane kernels (k_dp_regs / k_dp_long) when
+// it holds many.  Every kernel of both families evaluates this on the device.
+__device__ __forceinline__ bool wavefront_class(const DpArgs &a, uint32_t total, int cls)
+{
+    const uint32_t c2 = min(a.class_lo[2], total), c3 = min(a.class_lo[3], total);
+    const uint32_t n = cls == 2 ? c3 - c2 : total - c3;
+    return n <= (cls == 2 ? a.sys_limit : a.sys_limit / 2);
 }
 
 // Adds a wave's decisions to the per-path counters: two atomics per distinct
@@ -1306,7 +1318,7 @@ __global__ __launch_bounds__(DP_THREADS) void k_dp_regs(DpArgs a)
     const uint32_t total = *a.wl_count;
     // short list: from 16 columns up the wavefront kernels have the lower latency
     // (with few columns the skipped rows count for more, see k_dp_sys)
-    if (CLS >= 2 && total <= a.sys_limit) return;
+    if (CLS >= 2 && wavefront_class(a, total, CLS)) return;
     uint32_t lo, hi;
     class_range(a.class_lo, CLS, total, lo, hi);
     const uint32_t n_threads = gridDim.x * DP_THREADS;
@@ -1427,7 +1439,7 @@ __global__ __launch_bounds__(DP_THREADS) void k_dp_sys(DpArgs a)
     __shared__ uint16_t apath[G][GFAL_MAX_STEPS + 2 * PAD + 8];
     if (*a.wl_count > a.wl_capacity) return;              // overflow: see k_wl_scatter
     const uint32_t total = *a.wl_count;
-    if (total > a.sys_limit) return;                      // long list: k_dp_regs / k_dp_long
+    if (!wavefront_class(a, total, MC == 16 ? 2 : 3)) return;   // many entries: k_dp_regs / k_dp_long
     // MC = 16: class 2; MC = 64: class 3 and the entries of the last class that
     // fit (k_dp_long skips those on a short list); classes 0 and 1 always take
     // k_dp_regs, whose row skipping beats the wavefront for few columns
@@ -1532,7 +1544,7 @@ __global__ __launch_bounds__(DP_THREADS) void k_dp_long(DpArgs a)
         const bool live = w < hi;
         const DpEntry e = load_entry(a, w, live);
         // on a short list k_dp_sys<64> takes the entries of up to 64 steps
-        const bool mine = live && !(total <= a.sys_limit && e.m <= SYS_MAX_M);
+        const bool mine = live && !(wavefront_class(a, total, 3) && e.m <= SYS_MAX_M);
         // src/eval.cpp:92-98; both fills always run so the lanes of the wave
         // stay in step through the row loops (a dead lane has n = m = 0)
         StepsA A{e.astep, mine ? e.n : 0};
@@ -1584,7 +1596,9 @@ __global__ void k_fill_i32(int32_t *p, long long n, int32_t v)
 struct gfal_scorer {
     int device = 0;
     int n_cus = 256;
-    int64_t n_aln = 0, n_steps = 0;
+    int64_t n_aln = 0, n_steps = 0;      // this shard's alignments and their steps
+    int64_t n_aln_in = 0;                 // alignments given to create (all shards)
+    std::vector<uint8_t> owned;           // [n_aln_in] 1 = scored by this shard
     int32_t n_nodes = 0, n_local = 0, max_aln_len = 0;
     uint32_t n_empty = 0;
     int n_items = 0;
@@ -1603,7 +1617,7 @@ struct gfal_scorer {
     unsigned long long *d_worklist = nullptr;   // as pushed by k_scan
     unsigned long long *d_worklist_sorted = nullptr;
     uint32_t wl_capacity = 0;
-    uint32_t dp_sys_limit = 65536;   // see k_dp_sys
+    uint32_t dp_sys_limit = 8192;   // entries of class 2 (half of it: classes 3+), see wavefront_class()
     uint32_t *d_len_bins = nullptr;    // [3 * LEN_BINS] path-length counting sort
     int32_t *d_order = nullptr;        // [n_paths] slot -> caller's path index
     uint32_t *d_counts_slot = nullptr; // [3 * n_paths] counters by slot
@@ -1762,8 +1776,18 @@ int gfal_scorer_create_ex(const int32_t *aln_off, const int32_t *aln_steps,
                           const int32_t *universe, int32_t n_universe,
                           gfal_scorer **out)
 {
+    return gfal_scorer_create_sharded(aln_off, aln_steps, n_aln, n_nodes, device, universe,
+                                      n_universe, 0, 1, out);
+}
+
+int gfal_scorer_create_sharded(const int32_t *aln_off, const int32_t *aln_steps,
+                               int64_t n_aln, int32_t n_nodes, int device,
+                               const int32_t *universe, int32_t n_universe,
+                               int32_t shard_index, int32_t n_shards, gfal_scorer **out)
+{
     if (!out) return GFAL_E_ARG;
     *out = nullptr;
+    if (n_shards < 1 || shard_index < 0 || shard_index >= n_shards) return GFAL_E_ARG;
     if (n_aln < 0 || n_nodes < 0 || (n_aln > 0 && (!aln_off || aln_off[0] != 0)))
         return GFAL_E_ARG;
     if (n_universe < 0 || (n_universe > 0 && !universe)) return GFAL_E_ARG;
@@ -1801,7 +1825,7 @@ int gfal_scorer_create_ex(const int32_t *aln_off, const int32_t *aln_steps,
                     (long long)m, GFAL_MAX_STEPS);
             return GFAL_E_RANGE;
         }
-        if (m == 0) ++n_empty;
+        if (m == 0 && shard_index == 0) ++n_empty;   // zero-step alignments go to shard 0
         max_len = std::max(max_len, (int)m);
     }
     for (int64_t t = 0; t < S; ++t) {
@@ -1915,7 +1939,6 @@ int gfal_scorer_create_ex(const int32_t *aln_off, const int32_t *aln_steps,
         int32_t s = aln_steps[t];
         int32_t mapped = node_local[s >> 1];
         uint32_t lid = (uint32_t)(mapped >= 0 ? mapped : outside_lid);
-        ++hist[lid];
         local_steps[(size_t)t] = (uint16_t)((lid << 1) | ((uint32_t)s & 1u));
     }
 
@@ -1976,13 +1999,19 @@ int gfal_scorer_create_ex(const int32_t *aln_off, const int32_t *aln_steps,
     std::vector<uint16_t> item_len;
     std::vector<uint32_t> item_pairs, item_pbase;
     std::vector<int32_t> slot_orig;
-    item_steps.reserve((size_t)S + 64 * 64);
+    item_steps.reserve((size_t)S / (size_t)n_shards + 64 * 64);
+    uint64_t global_item = 0;
+    int64_t own_aln = n_empty, own_steps = 0;
     for (int m = 1; m <= max_len; ++m) {
         std::vector<int32_t> &idx = by_len[(size_t)m];
         if (idx.empty()) continue;
         const uint16_t *ls = local_steps.data();
         for (size_t at = 0; at < idx.size(); at += WAVE) {
             size_t cnt = std::min<size_t>(WAVE, idx.size() - at);
+            // shards are cut AFTER the global sort, item by item: a shard's items
+            // are a subset of the unsharded ones (same lanes side by side), so the
+            // scan kernel does on 1/n of the items exactly 1/n of the work
+            if ((int32_t)(global_item++ % (uint64_t)n_shards) != shard_index) continue;
             size_t base = item_steps.size();
             item_base.push_back((uint32_t)(base / WAVE));
             item_len.push_back((uint16_t)m);
@@ -2001,6 +2030,9 @@ int gfal_scorer_create_ex(const int32_t *aln_off, const int32_t *aln_steps,
                             (uint32_t)px[2 * k + 1] |
                             ((2 * k + 2 < m) ? ((uint32_t)px[2 * k + 2] << 16) : 0u);
                     slot_orig.push_back(idx[at + l]);
+                    for (int t = 0; t < m; ++t) ++hist[px[t] >> 1];
+                    ++own_aln;
+                    own_steps += m;
                 } else {
                     slot_orig.push_back(-1);
                 }
@@ -2016,8 +2048,16 @@ int gfal_scorer_create_ex(const int32_t *aln_off, const int32_t *aln_steps,
     gfal_scorer *s = new (std::nothrow) gfal_scorer();
     if (!s) return GFAL_E_NOMEM;
     s->device = device;
-    s->n_aln = n_aln;
-    s->n_steps = S;
+    s->n_aln = own_aln;
+    s->n_aln_in = n_aln;
+    s->n_steps = own_steps;
+    // which of the caller's alignments this shard scores (pair_scores)
+    s->owned.assign((size_t)n_aln, 0);
+    for (int32_t orig : slot_orig)
+        if (orig >= 0) s->owned[(size_t)orig] = 1;
+    if (shard_index == 0)
+        for (int64_t k = 0; k < n_aln; ++k)
+            if (aln_off[k + 1] == aln_off[k]) s->owned[(size_t)k] = 1;
     s->n_nodes = n_nodes;
     s->n_local = n_local;
     s->max_aln_len = max_len;
@@ -2067,9 +2107,9 @@ int gfal_scorer_create_ex(const int32_t *aln_off, const int32_t *aln_steps,
     CREATE_TRY(hipMemset(s->d_status, 0, 4 * sizeof(uint32_t)));
     // worklist: at least one entry per alignment, so a single path always fits
     if (const char *env = getenv("GFAL_DP_SYS_LIMIT")) s->dp_sys_limit = (uint32_t)atoll(env);
-    s->wl_capacity = (uint32_t)std::max<int64_t>(n_aln, (int64_t)1 << 22);
+    s->wl_capacity = (uint32_t)std::max<int64_t>(own_aln, (int64_t)1 << 22);
     if (const char *env = getenv("GFAL_DEBUG_WL_CAPACITY"))   // tests: force the overflow path
-        s->wl_capacity = (uint32_t)std::max<int64_t>(n_aln, atoll(env));
+        s->wl_capacity = (uint32_t)std::max<int64_t>(own_aln, atoll(env));
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_worklist),
                          (size_t)s->wl_capacity * sizeof(unsigned long long)));
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_worklist_sorted),
@@ -2437,21 +2477,22 @@ int gfal_scorer_pair_scores(gfal_scorer *s, const int32_t *path_steps, int32_t n
                        s->n_empty, 0, L, nullptr, s->d_images, s->d_counts, s->d_status);
     HIP_TRY(hipGetLastError());
 
+    // device results are indexed like the caller's alignments (all shards)
+    const size_t n_in = (size_t)s->n_aln_in;
     int32_t *d_fw = nullptr, *d_rc = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_fw), (size_t)s->n_aln * sizeof(int32_t)));
-    hipError_t e2 = hipMalloc(reinterpret_cast<void **>(&d_rc),
-                              (size_t)s->n_aln * sizeof(int32_t));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_fw), n_in * sizeof(int32_t)));
+    hipError_t e2 = hipMalloc(reinterpret_cast<void **>(&d_rc), n_in * sizeof(int32_t));
     if (e2 != hipSuccess) {
         (void)hipFree(d_fw);
         set_err("hipMalloc failed: %s", hipGetErrorString(e2));
         return GFAL_E_NOMEM;
     }
     // zero-step alignments: both tracebacks are free (score 0)
-    unsigned fill_blocks = (unsigned)((s->n_aln + 255) / 256);
+    unsigned fill_blocks = (unsigned)((n_in + 255) / 256);
     hipLaunchKernelGGL(k_fill_i32, dim3(fill_blocks), dim3(256), 0, s->stream, d_fw,
-                       (long long)s->n_aln, 0);
+                       (long long)n_in, 0);
     hipLaunchKernelGGL(k_fill_i32, dim3(fill_blocks), dim3(256), 0, s->stream, d_rc,
-                       (long long)s->n_aln, 0);
+                       (long long)n_in, 0);
     if (s->n_items > 0) {
         Items items{s->d_item_steps, s->d_item_base, s->d_item_len, s->d_item_pairs,
                     s->d_item_pbase, s->n_items};
@@ -2464,13 +2505,14 @@ int gfal_scorer_pair_scores(gfal_scorer *s, const int32_t *path_steps, int32_t n
                                s->stream, items, s->d_slot_orig, s->d_images, L,
                                s->d_rows, d_fw, d_rc);
     }
+    std::vector<int32_t> h_fw(n_in), h_rc(n_in);
     hipError_t e3 = hipGetLastError();
     if (e3 == hipSuccess)
-        e3 = hipMemcpyAsync(fw, d_fw, (size_t)s->n_aln * sizeof(int32_t),
-                            hipMemcpyDeviceToHost, s->stream);
+        e3 = hipMemcpyAsync(h_fw.data(), d_fw, n_in * sizeof(int32_t), hipMemcpyDeviceToHost,
+                            s->stream);
     if (e3 == hipSuccess)
-        e3 = hipMemcpyAsync(rc_out, d_rc, (size_t)s->n_aln * sizeof(int32_t),
-                            hipMemcpyDeviceToHost, s->stream);
+        e3 = hipMemcpyAsync(h_rc.data(), d_rc, n_in * sizeof(int32_t), hipMemcpyDeviceToHost,
+                            s->stream);
     if (e3 == hipSuccess) e3 = hipStreamSynchronize(s->stream);
     (void)hipFree(d_fw);
     (void)hipFree(d_rc);
@@ -2478,6 +2520,13 @@ int gfal_scorer_pair_scores(gfal_scorer *s, const int32_t *path_steps, int32_t n
         set_err("pair_scores: %s", hipGetErrorString(e3));
         return GFAL_E_HIP;
     }
+    // only this shard's alignments are written: the shards of one alignment set
+    // fill one pair of arrays between them
+    for (size_t k = 0; k < n_in; ++k)
+        if (s->owned[k]) {
+            fw[k] = h_fw[k];
+            rc_out[k] = h_rc[k];
+        }
     s->last_stream = s->stream;
     s->have_last = true;
     return gfal_scorer_sync_status(s);

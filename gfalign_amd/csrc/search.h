@@ -176,75 +176,30 @@ public:
         n_aln_ = a.size();
         if (n_aln_ == 0) return true;
         n_devices = (int)std::max<int64_t>(1, std::min<int64_t>(n_devices, n_aln_));
-        if (n_devices == 1) {      // one shard: the alignments as they are
-            members_.assign(1, {});
-            gfal_scorer *h = nullptr;
-            int rc = gfal_scorer_create_ex(a.off.data(), a.steps.data(), n_aln_, n_nodes,
-                                           first_device, universe.data(),
-                                           (int32_t)universe.size(), &h);
-            if (rc != GFAL_OK) {
-                fprintf(stderr, "Error: scorer: %s (%s)\n", gfal_strerror(rc), gfal_last_error());
+        // every device gets the whole set and keeps every n_devices-th group of the
+        // scorer's own sorted order (gfal_scorer_create_sharded): the shards
+        // partition the set and balance by construction.  Creation (a host-side
+        // sort each) runs on all devices at once.
+        shards_.assign((size_t)n_devices, nullptr);
+        std::vector<int> rcs((size_t)n_devices, GFAL_OK);
+        std::vector<std::string> errs((size_t)n_devices);
+        auto make = [&](int d) {
+            rcs[(size_t)d] = gfal_scorer_create_sharded(
+                a.off.data(), a.steps.data(), n_aln_, n_nodes,
+                share_device ? first_device : first_device + d, universe.data(),
+                (int32_t)universe.size(), d, n_devices, &shards_[(size_t)d]);
+            if (rcs[(size_t)d] != GFAL_OK) errs[(size_t)d] = gfal_last_error();
+        };
+        std::vector<std::thread> threads;
+        for (int d = 1; d < n_devices; ++d) threads.emplace_back(make, d);
+        make(0);
+        for (auto &t : threads) t.join();
+        for (int d = 0; d < n_devices; ++d)
+            if (rcs[(size_t)d] != GFAL_OK) {
+                fprintf(stderr, "Error: scorer: %s (%s)\n", gfal_strerror(rcs[(size_t)d]),
+                        errs[(size_t)d].c_str());
                 return false;
             }
-            shards_.push_back(h);
-            return true;
-        }
-        // Which device owns which alignment: all copies of one alignment go to
-        // one device (the scan kernel is fastest on runs of identical
-        // alignments), groups are dealt heaviest-first in serpentine order so
-        // the step counts balance.  Same policy as gfalign_amd/shard.py.
-        std::vector<uint64_t> hash((size_t)n_aln_);
-        for (int64_t k = 0; k < n_aln_; ++k) {
-            uint64_t h = 0x9E3779B97F4A7C15ull;
-            for (int32_t t = a.off[(size_t)k]; t < a.off[(size_t)k + 1]; ++t) {
-                h ^= (uint64_t)(uint32_t)a.steps[(size_t)t] + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
-                h *= 0xBF58476D1CE4E5B9ull;
-            }
-            hash[(size_t)k] = h;
-        }
-        std::vector<int64_t> idx((size_t)n_aln_);
-        for (int64_t k = 0; k < n_aln_; ++k) idx[(size_t)k] = k;
-        std::sort(idx.begin(), idx.end(), [&](int64_t x, int64_t y) {
-            return hash[(size_t)x] != hash[(size_t)y] ? hash[(size_t)x] < hash[(size_t)y] : x < y;
-        });
-        struct Group { size_t begin, end; int64_t weight; };
-        std::vector<Group> groups;
-        for (size_t i = 0; i < idx.size();) {
-            size_t j = i;
-            int64_t wgt = 0;
-            while (j < idx.size() && hash[(size_t)idx[j]] == hash[(size_t)idx[i]]) {
-                wgt += a.off[(size_t)idx[j] + 1] - a.off[(size_t)idx[j]];
-                ++j;
-            }
-            groups.push_back({i, j, wgt});
-            i = j;
-        }
-        std::stable_sort(groups.begin(), groups.end(),
-                         [](const Group &x, const Group &y) { return x.weight > y.weight; });
-        members_.assign((size_t)n_devices, {});
-        for (size_t gi = 0; gi < groups.size(); ++gi) {
-            const size_t turn = gi % (2 * (size_t)n_devices);
-            const size_t d = turn < (size_t)n_devices ? turn : 2 * (size_t)n_devices - 1 - turn;
-            for (size_t i = groups[gi].begin; i < groups[gi].end; ++i) members_[d].push_back(idx[i]);
-        }
-        for (int d = 0; d < n_devices; ++d) {
-            std::sort(members_[(size_t)d].begin(), members_[(size_t)d].end());
-            std::vector<int32_t> off{0}, steps;
-            for (int64_t k : members_[(size_t)d]) {
-                steps.insert(steps.end(), a.steps.begin() + a.off[(size_t)k],
-                             a.steps.begin() + a.off[(size_t)k + 1]);
-                off.push_back((int32_t)steps.size());
-            }
-            gfal_scorer *h = nullptr;
-            int rc = gfal_scorer_create_ex(off.data(), steps.data(), (int64_t)off.size() - 1,
-                                           n_nodes, share_device ? first_device : first_device + d,
-                                           universe.data(), (int32_t)universe.size(), &h);
-            if (rc != GFAL_OK) {
-                fprintf(stderr, "Error: scorer: %s (%s)\n", gfal_strerror(rc), gfal_last_error());
-                return false;
-            }
-            shards_.push_back(h);
-        }
         return true;
     }
     bool score(const std::vector<int32_t> &off, const std::vector<int32_t> &steps, bool filter,
@@ -288,27 +243,12 @@ public:
     {
         fw.assign((size_t)n_aln_, 0);
         rc.assign((size_t)n_aln_, 0);
-        if (shards_.size() == 1 && members_[0].empty()) {   // one shard, input order
-            int err = gfal_scorer_pair_scores(shards_[0], path.data(), (int32_t)path.size(),
-                                              fw.data(), rc.data());
+        for (gfal_scorer *h : shards_) {   // every shard writes the entries of its own alignments
+            int err = gfal_scorer_pair_scores(h, path.data(), (int32_t)path.size(), fw.data(),
+                                              rc.data());
             if (err != GFAL_OK) {
                 fprintf(stderr, "Error: scorer: %s (%s)\n", gfal_strerror(err), gfal_last_error());
                 return false;
-            }
-            return true;
-        }
-        for (size_t d = 0; d < shards_.size(); ++d) {
-            const std::vector<int64_t> &mem = members_[d];
-            std::vector<int32_t> f(mem.size()), r(mem.size());
-            int err = gfal_scorer_pair_scores(shards_[d], path.data(), (int32_t)path.size(),
-                                              f.data(), r.data());
-            if (err != GFAL_OK) {
-                fprintf(stderr, "Error: scorer: %s (%s)\n", gfal_strerror(err), gfal_last_error());
-                return false;
-            }
-            for (size_t i = 0; i < mem.size(); ++i) {
-                fw[(size_t)mem[i]] = f[i];
-                rc[(size_t)mem[i]] = r[i];
             }
         }
         return true;
@@ -318,7 +258,6 @@ public:
 
 private:
     std::vector<gfal_scorer *> shards_;
-    std::vector<std::vector<int64_t>> members_;   // per shard: alignment indices, ascending
     int64_t n_aln_ = 0;
     uint64_t dp_pairs_ = 0;
 };

@@ -37,6 +37,9 @@ EXPORTS = {
     "gfal_device_count": (ctypes.c_int, []),
     "gfal_scorer_create": (ctypes.c_int, [_i32p, _i32p, ctypes.c_int64, ctypes.c_int32,
                                           ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    "gfal_scorer_create_sharded": (ctypes.c_int, [_i32p, _i32p, ctypes.c_int64, ctypes.c_int32,
+                                                  ctypes.c_int, _i32p, ctypes.c_int32, ctypes.c_int32,
+                                                  ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p)]),
     "gfal_scorer_create_ex": (ctypes.c_int, [_i32p, _i32p, ctypes.c_int64, ctypes.c_int32,
                                              ctypes.c_int, _i32p, ctypes.c_int32,
                                              ctypes.POINTER(ctypes.c_void_p)]),
@@ -113,12 +116,21 @@ def pack_step(node_id, orientation):
 class Scorer:
     """One shard of alignments resident on one MI355X."""
 
-    def __init__(self, aln_off, aln_steps, n_nodes, device=0, universe=None):
+    def __init__(self, aln_off, aln_steps, n_nodes, device=0, universe=None, shard=None):
+        """shard = (index, count): this scorer keeps its share of the alignment
+        set given in full (gfal_scorer_create_sharded)."""
         self._lib = load_library()
         self._h = ctypes.c_void_p()
         aln_off, aln_steps = _i32(aln_off), _i32(aln_steps)
         self.n_aln = len(aln_off) - 1
-        if universe is None:
+        if shard is not None:
+            uni = None if universe is None else _i32(universe)
+            _check(self._lib.gfal_scorer_create_sharded(
+                _ptr(aln_off, ctypes.c_int32), _ptr(aln_steps, ctypes.c_int32),
+                self.n_aln, int(n_nodes), int(device),
+                None if uni is None else _ptr(uni, ctypes.c_int32), 0 if uni is None else len(uni),
+                int(shard[0]), int(shard[1]), ctypes.byref(self._h)))
+        elif universe is None:
             _check(self._lib.gfal_scorer_create(
                 _ptr(aln_off, ctypes.c_int32), _ptr(aln_steps, ctypes.c_int32),
                 self.n_aln, int(n_nodes), int(device), ctypes.byref(self._h)))
@@ -170,11 +182,17 @@ class Scorer:
     def sync_status(self):
         _check(self._lib.gfal_scorer_sync_status(self._h))
 
-    def pair_scores(self, path_steps):
-        """(fw, rc) traceback scores of every alignment vs one path."""
+    def pair_scores(self, path_steps, out=None):
+        """(fw, rc) traceback scores of every alignment vs one path.  A shard
+        writes the entries of its own alignments only: pass the same `out`
+        arrays to every shard of a set to fill them."""
         path_steps = _i32(path_steps)
-        fw = np.zeros(self.n_aln, np.int32)
-        rc = np.zeros(self.n_aln, np.int32)
+        if out is None:
+            fw = np.zeros(self.n_aln, np.int32)
+            rc = np.zeros(self.n_aln, np.int32)
+        else:
+            fw, rc = out
+            assert fw.dtype == np.int32 and rc.dtype == np.int32 and len(fw) == len(rc) == self.n_aln
         _check(self._lib.gfal_scorer_pair_scores(
             self._h, _ptr(path_steps, ctypes.c_int32), len(path_steps),
             _ptr(fw, ctypes.c_int32), _ptr(rc, ctypes.c_int32)))

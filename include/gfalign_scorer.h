@@ -94,6 +94,20 @@ int gfal_scorer_create_ex(const int32_t *aln_off, const int32_t *aln_steps,
                           const int32_t *universe, int32_t n_universe,
                           gfal_scorer **out);
 
+/*
+ * One of n_shards shards of the SAME alignment set (multi-GPU):
+ * every shard is created from the complete arrays and keeps every n_shards-th
+ * group of 64 alignments of the length- and content-sorted order the kernels
+ * use, so the shards of one set partition it, balance by construction, and
+ * each does 1/n_shards of the unsharded work.  The counters of the shards add
+ * up to the unsharded counters (integer sums: any reduction order).
+ * gfal_scorer_create_ex is shard 0 of 1.
+ */
+int gfal_scorer_create_sharded(const int32_t *aln_off, const int32_t *aln_steps,
+                               int64_t n_aln, int32_t n_nodes, int device,
+                               const int32_t *universe, int32_t n_universe,
+                               int32_t shard_index, int32_t n_shards, gfal_scorer **out);
+
 void gfal_scorer_destroy(gfal_scorer *s);
 
 /*
@@ -134,8 +148,10 @@ int gfal_scorer_sync_status(gfal_scorer *s);
 /*
  * Traceback scores of ONE path against every alignment of the shard, both
  * orientations (src/eval.cpp:92-93): what evalPath prints per alignment
- * (src/eval.cpp:100-102).  fw, rc: host int32 [n_aln], in the order the
- * alignments were given to gfal_scorer_create.
+ * (src/eval.cpp:100-102).  fw, rc: host int32 [n_aln given to create], in the
+ * order the alignments were given; a shard of gfal_scorer_create_sharded
+ * writes the entries of its own alignments only, so calling every shard with
+ * the same two arrays fills them.
  */
 int gfal_scorer_pair_scores(gfal_scorer *s, const int32_t *path_steps, int32_t n,
                             int32_t *fw, int32_t *rc);

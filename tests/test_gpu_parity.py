@@ -250,6 +250,30 @@ def test_universe_folds_outside_nodes(gpu):
         assert e.value.code == -2
 
 
+def test_sharded_scorers_fill_pair_scores_between_them(gpu):
+    """evalPath over several devices: every shard writes the fw / rc scores of
+    its own alignments into the same arrays (zero-step alignments included)."""
+    rnd = random.Random(52)
+    alns, paths = walk_case(rnd, 30, 200, 700, 3, 20)
+    alns[5] = []
+    alns[77] = []
+    aoff, ast = csr(alns)
+    path = paths[0]
+    with Scorer(aoff, ast, 64) as sc:
+        exp_fw, exp_rc = sc.pair_scores(path)
+    fw = np.full(len(alns), -12345, np.int32)
+    rc = np.full(len(alns), -12345, np.int32)
+    owned_total = 0
+    for k in range(4):
+        with Scorer(aoff, ast, 64, shard=(k, 4)) as sc:
+            owned_total += sc.info()["n_aln"]
+            sc.pair_scores(path, out=(fw, rc))
+    assert owned_total == len(alns)
+    assert np.array_equal(fw, exp_fw) and np.array_equal(rc, exp_rc)
+    ofw, orc = oracle.pair_scores(aoff, ast, path)
+    assert np.array_equal(fw, ofw) and np.array_equal(rc, orc)
+
+
 def test_worklist_overflow_splits_the_batch(gpu, monkeypatch):
     """More exact-DP pairs than the worklist holds: the blocking API halves the
     batch until every piece fits (a single path always does)."""

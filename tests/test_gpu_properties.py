@@ -60,6 +60,29 @@ def test_shards_add_up(full, tangle):
     assert np.array_equal(acc[2], una)
 
 
+@pytest.mark.parametrize("n_shards", [3, 8])
+def test_sharded_create_partitions_the_set(full, tangle, n_shards):
+    """gfal_scorer_create_sharded (what bench.py --gpus N and `--devices N` use):
+    the shards of one alignment set own every alignment exactly once, balance
+    to within one item per length, and their counters add up to the unsharded
+    ones at the full BASELINE size."""
+    _, (bad, good, una) = full
+    t = tangle
+    acc = [np.zeros(t.P, np.uint64) for _ in range(3)]
+    n_owned, steps_owned = [], []
+    for k in range(n_shards):
+        with Scorer(t.aln_off, t.aln_steps, t.V, shard=(k, n_shards)) as sc:
+            info = sc.info()
+            n_owned.append(info["n_aln"])
+            steps_owned.append(info["n_steps"])
+            for a, part in zip(acc, sc.evaluate_paths(t.path_off, t.path_steps, True)):
+                a += part
+    assert sum(n_owned) == t.N and sum(steps_owned) == int(t.aln_off[-1])
+    assert max(steps_owned) - min(steps_owned) < 0.01 * sum(steps_owned) / n_shards
+    assert np.array_equal(acc[0], bad) and np.array_equal(acc[1], good)
+    assert np.array_equal(acc[2], una)
+
+
 def test_truth_walk_explains_every_clean_alignment(full, tangle):
     """Scoring the whole truth walk: every alignment that is an exact sub-walk
     (either strand) is good; counted here independently with numpy."""
