@@ -274,7 +274,88 @@ int run_filter(const Options &o, std::vector<GafRecord> &recs, const AlignmentTo
 }
 
 // ------------------------------------------------------------- evalGFA ---
-int run_eval_gfa(const Options &o, std::vector<GafRecord> &recs, AlignmentTotals totals)
+// evalGFA -o: how many read alignments walk over every link of the graph,
+// written as an RC:i tag on the L lines (reference src/eval.cpp:34-61 over the
+// edge multigraph of src/alignments.cpp:353-403, restated step for step: the
+// forward edge and its reverse twin are counted together, and a link that is its
+// own reverse is counted twice from its second sighting on, as there).
+// The reference hands the tagged graph to gfalibs' GFA writer, which is not in
+// the tree: here the input GFA is written back line by line with the tag
+// appended to every L line, to the file named by -o, or to stdout when -o names
+// a format ("gfa") rather than a file.  The tag values are pinned by the
+// in-tree code; the surrounding GFA text is "parity unpinned" (no fixture).
+struct WeightedEdge {
+    char from_orient;
+    uint32_t to;
+    char to_orient;
+    unsigned weight;
+    bool same(const WeightedEdge &e) const
+    {
+        return from_orient == e.from_orient && to == e.to && to_orient == e.to_orient;
+    }
+};
+
+int tag_edges_and_write(const Options &o, const Graph &g, const std::vector<GafRecord> &recs)
+{
+    std::vector<std::vector<WeightedEdge>> adj(g.headers.size());
+    auto find = [](std::vector<WeightedEdge> &lst, const WeightedEdge &e) -> WeightedEdge * {
+        for (auto &x : lst)
+            if (x.same(e)) return &x;
+        return nullptr;
+    };
+    std::vector<std::pair<std::string, char>> nodes;
+    for (const GafRecord &r : recs) {                         // src/alignments.cpp:361-399
+        gaf_path_nodes(r.path, nodes);                        // :407-445 consecutive pairs
+        for (size_t k = 0; k + 1 < nodes.size(); ++k) {
+            if (g.headers.empty()) break;
+            const uint32_t id1 = g.id_or_zero(nodes[k].first), id2 = g.id_or_zero(nodes[k + 1].first);
+            const WeightedEdge fw{nodes[k].second, id2, nodes[k + 1].second, 1};
+            const WeightedEdge rv{flip(nodes[k + 1].second), id1, flip(nodes[k].second), 1};
+            if (WeightedEdge *hit = find(adj[id1], fw)) {
+                ++hit->weight;
+                if (WeightedEdge *twin = find(adj[id2], rv)) ++twin->weight;
+            } else {
+                adj[id1].push_back(fw);
+                if (!find(adj[id2], rv)) adj[id2].push_back(rv);
+            }
+        }
+    }
+    std::ifstream in(o.gfa);
+    if (!in) {
+        fprintf(stderr, "Error: cannot open %s\n", o.gfa.c_str());
+        return 1;
+    }
+    std::ofstream file;
+    const bool to_file = o.out_file.find('.') != std::string::npos;
+    if (to_file) {
+        file.open(o.out_file);
+        if (!file) {
+            fprintf(stderr, "Error: cannot write %s\n", o.out_file.c_str());
+            return 1;
+        }
+    }
+    std::ostream &out = to_file ? static_cast<std::ostream &>(file) : std::cout;
+    std::string line;
+    while (std::getline(in, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        if (!line.empty() && line[0] == 'L') {
+            auto cols = split(line, '\t');
+            unsigned weight = 0;                               // src/eval.cpp:46-55
+            if (cols.size() >= 5 && !cols[2].empty() && !cols[4].empty()) {
+                auto a = g.ids.find(cols[1]), b = g.ids.find(cols[3]);
+                if (a != g.ids.end() && b != g.ids.end())
+                    if (WeightedEdge *hit = find(adj[a->second], WeightedEdge{cols[2][0], b->second, cols[4][0], 0}))
+                        weight = hit->weight;
+            }
+            out << line << "\tRC:i:" << weight << "\n";        // :57-58
+        } else {
+            out << line << "\n";
+        }
+    }
+    return 0;
+}
+
+int run_eval_gfa(const Options &o, const Graph &g, std::vector<GafRecord> &recs, AlignmentTotals totals)
 {
     if (o.gaf.empty()) return 0;
     std::stable_sort(recs.begin(), recs.end(),
@@ -317,11 +398,7 @@ int run_eval_gfa(const Options &o, std::vector<GafRecord> &recs, AlignmentTotals
     // printed and the --sort-alignment output branch of
     // src/input-gfalign.cpp:88-91 is never taken (validateFiles/test.2.tst)
     print_stats(totals, recs.size(), false);
-    if (!o.out_file.empty()) {
-        fprintf(stderr, "Error: evalGFA -o (RC:i edge tagging + GFA output) is not part of this "
-                        "build.\n");
-        return 1;
-    }
+    if (!o.out_file.empty()) return tag_edges_and_write(o, g, recs);   // src/input-gfalign.cpp:93-97
     return 0;
 }
 
@@ -458,7 +535,7 @@ int main(int argc, char **argv)
     }
 
     switch (o.mode) {
-    case 1: return run_eval_gfa(o, recs, totals);
+    case 1: return run_eval_gfa(o, g, recs, totals);
     case 3: {
         const double t_read = gfal::now_s();
         if (!g.ids.count(o.source) || !g.ids.count(o.destination)) {

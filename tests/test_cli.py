@@ -66,6 +66,76 @@ def test_reference_evalgfa_summaries(cli, name):
     assert rc == 0 and out == expected
 
 
+def _edge_weights(gaf_paths, ids):
+    """reference src/alignments.cpp:353-403 restated: adjacency lists of
+    [from_orient, to, to_orient, weight]; returns them."""
+    flip = {"+": "-", "-": "+"}
+    adj = {v: [] for v in ids.values()}
+
+    def find(lst, e):
+        for x in lst:
+            if x[:3] == e[:3]:
+                return x
+        return None
+
+    for path in gaf_paths:
+        nodes, i = [], 0
+        while i < len(path):
+            j = i + 1
+            while j < len(path) and path[j] not in "<>":
+                j += 1
+            nodes.append((ids.get(path[i + 1:j], 0), "+" if path[i] == ">" else "-"))
+            i = j
+        for (a, ao), (b, bo) in zip(nodes, nodes[1:]):
+            fw, rv = [ao, b, bo, 1], [flip[bo], a, flip[ao], 1]
+            hit = find(adj[a], fw)
+            if hit is None:
+                adj[a].append(fw)
+                if find(adj[b], rv) is None:
+                    adj[b].append(rv)
+            else:
+                hit[3] += 1
+                find(adj[b], rv)[3] += 1
+    return adj
+
+
+def test_evalgfa_tags_links_with_read_counts(cli, tmp_path):
+    """evalGFA -o: RC:i tag per L line = how many alignments walk the link in
+    either direction (src/eval.cpp:34-61); a link that is its own reverse
+    (a+ -> a-) counts twice from the second sighting on, as in the reference.
+    The GFA text around the tag is this build's (gfalibs' writer is absent)."""
+    gfa = tmp_path / "g.gfa"
+    gaf = tmp_path / "a.gaf"
+    links = [("a", "+", "b", "+"), ("b", "+", "c", "-"), ("a", "+", "a", "-"), ("c", "+", "a", "+"),
+             ("b", "-", "a", "-")]
+    gfa.write_text("H\tVN:Z:1.0\n" + "".join("S\t%s\tACGT\n" % n for n in "abc") +
+                   "".join("L\t%s\t%s\t%s\t%s\t0M\n" % l for l in links))
+    paths = [">a>b<c", ">c<b<a", ">a<a", ">a<a", ">a<a>b", "<b<a", ">c", ">b>zzz"]
+    gaf.write_text("".join("r%d\t10\t0\t10\t+\t%s\t30\t0\t10\t10\t10\t60\n" % (k, p)
+                           for k, p in enumerate(paths)))
+    out = tmp_path / "tagged.gfa"
+    rc, stdout, err = run(cli, ["evalGFA", "-f", str(gfa), "-g", str(gaf), "-o", str(out)])
+    assert rc == 0, err
+    assert stdout.startswith("+++Alignment summary+++")
+    ids = {"a": 0, "b": 1, "c": 2}
+    adj = _edge_weights(paths, ids)
+    got = [l.split("\t") for l in out.read_text().splitlines()]
+    assert [l for l in got if l[0] != "L"] == [l.split("\t") for l in gfa.read_text().splitlines()
+                                               if not l.startswith("L")]
+    tagged = [l for l in got if l[0] == "L"]
+    assert len(tagged) == len(links)
+    for l, (a, ao, b, bo) in zip(tagged, links):
+        hit = [e for e in adj[ids[a]] if e[:3] == [ao, ids[b], bo]]
+        want = hit[0][3] if hit else 0
+        assert l[:6] == ["L", a, ao, b, bo, "0M"] and l[6] == "RC:i:%d" % want, (l, want)
+    # spot values: a+b+ walked by >a>b<c, >a<a>b and, backwards, by <b<a; the
+    # self-reverse link a+a- three times = 1 + 2 + 2
+    assert tagged[0][6] == "RC:i:3" and tagged[2][6] == "RC:i:5" and tagged[3][6] == "RC:i:0"
+    # -o naming a format writes to stdout after the summary
+    rc, stdout, err = run(cli, ["evalGFA", "-f", str(gfa), "-g", str(gaf), "-o", "gfa"])
+    assert rc == 0 and stdout.splitlines()[-len(got):] == out.read_text().splitlines()
+
+
 def test_filter_min_nodes(cli, tmp_path):
     rc, out, _ = run(cli, ["filter", "-g", REF_FILES + "/random3.gaf", "-n",
                            REF_FILES + "/random3.filter_nodelist.ls", "-o", "x.gaf",
