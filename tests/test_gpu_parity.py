@@ -274,6 +274,30 @@ def test_sharded_scorers_fill_pair_scores_between_them(gpu):
     assert np.array_equal(fw, ofw) and np.array_equal(rc, orc)
 
 
+def test_more_than_32k_paths_in_one_batch(gpu):
+    """Batches above 32 768 paths sort by length with the three-kernel counting
+    sort instead of the one-workgroup one; results are per path either way."""
+    rnd = random.Random(61)
+    alns, base = walk_case(rnd, 12, 60, 300, 40, 8)
+    paths = [base[k % len(base)][:rnd.randint(1, 30)] for k in range(33000)]
+    aoff, ast = csr(alns)
+    poff, pst = csr(paths)
+    with Scorer(aoff, ast, 16) as sc:
+        bad, good, una = sc.evaluate_paths(poff, pst, True)
+        # the same paths in small batches (one-workgroup sort)
+        for lo in (0, 15000, 32990):
+            hi = min(lo + 10, len(paths))
+            o2, s2 = csr(paths[lo:hi])
+            b2, g2, u2 = sc.evaluate_paths(o2, s2, True)
+            assert np.array_equal(b2, bad[lo:hi]) and np.array_equal(g2, good[lo:hi])
+            assert np.array_equal(u2, una[lo:hi])
+    sample = list(range(0, len(paths), 1500))
+    o3, s3 = csr([paths[k] for k in sample])
+    eb, eg, eu = oracle.evaluate_paths(aoff, ast, o3, s3, True)
+    assert np.array_equal(bad[sample], eb) and np.array_equal(good[sample], eg)
+    assert np.array_equal(una[sample], eu)
+
+
 def test_worklist_overflow_splits_the_batch(gpu, monkeypatch):
     """More exact-DP pairs than the worklist holds: the blocking API halves the
     batch until every piece fits (a single path always does)."""
