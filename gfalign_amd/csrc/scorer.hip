@@ -673,7 +673,12 @@ __device__ __forceinline__ void scan_item(const ScanArgs &a, const TileView &tv,
         const lanemask found_m = subpath_search<K, MC>(pairs, M, o0, head, cv) & in_m;
         const lanemask open_m = in_m & ~found_m;
         lanemask bad_m = 0;
+#if defined(GFAL_ABLATE) && GFAL_ABLATE == 6      // timing probe: no overhang triage
+        bad_m = open_m;
+        if (false) {
+#else
         if (open_m != 0) {
+#endif
             // B is not a subpath and m <= n: the traceback stays free only if a
             // proper suffix of B (or of rc(B)) equals a prefix of the path
             // ("start-overhang").  Exact test; survivors go to the DP kernels.
@@ -833,6 +838,8 @@ __global__ __launch_bounds__(SCAN_THREADS, 6) void k_scan(ScanArgs a)
     __syncthreads();
 
     WaveCounts wc;                        // lane p: path0 + p
+    // (item headers through scalar loads -- `it` made uniform with readfirstlane --
+    // were measured 7 % slower: s_load shares the lgkm counter with the LDS reads)
     for (int it = chunk + wave * a.n_chunks; it < a.items.n_items;
          it += SCAN_WAVES * a.n_chunks) {
         const int M = __builtin_amdgcn_readfirstlane((int)a.items.len[it]);
