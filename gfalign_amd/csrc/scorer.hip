@@ -28,6 +28,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -1794,6 +1795,16 @@ int gfal_scorer_create_sharded(const int32_t *aln_off, const int32_t *aln_steps,
 {
     if (!out) return GFAL_E_ARG;
     *out = nullptr;
+    // GFAL_DEBUG_TIMING=1: where the host side of create spends its time (stderr)
+    const bool timing = getenv("GFAL_DEBUG_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto mark = [&](const char *what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "create: %-28s %.3f s\n", what,
+                std::chrono::duration<double>(now - t_prev).count());
+        t_prev = now;
+    };
     if (n_shards < 1 || shard_index < 0 || shard_index >= n_shards) return GFAL_E_ARG;
     if (n_aln < 0 || n_nodes < 0 || (n_aln > 0 && (!aln_off || aln_off[0] != 0)))
         return GFAL_E_ARG;
@@ -1844,6 +1855,7 @@ int gfal_scorer_create_sharded(const int32_t *aln_off, const int32_t *aln_steps,
         if (node_local[s >> 1] == -1) node_local[s >> 1] = 0;
         else if (node_local[s >> 1] == -2) any_outside = true;
     }
+    mark("validate");
     // Local ids follow a walk over the graph the alignments themselves trace
     // out (consecutive steps = an edge, weight = how often): depth-first along
     // the heaviest unvisited edge.  Nodes that are neighbours on the tangle get
@@ -1930,6 +1942,7 @@ int gfal_scorer_create_sharded(const int32_t *aln_off, const int32_t *aln_steps,
             if (node_local[v] == 0) walk_from((uint32_t)v);
         for (uint32_t v : visit_order) node_local[v] = n_local++;
     }
+    mark("node numbering");
     // every node outside the universe shares one local id: no path can carry
     // it, so such steps only ever fail the filter / a comparison, and their
     // histogram bin keeps `unaligned` exact
@@ -1949,6 +1962,7 @@ int gfal_scorer_create_sharded(const int32_t *aln_off, const int32_t *aln_steps,
         local_steps[(size_t)t] = (uint16_t)((lid << 1) | ((uint32_t)s & 1u));
     }
 
+    mark("local steps");
     // alignments of one length together, ordered by content so the lanes of a
     // wave look at neighbouring table entries and take the same branches
     std::vector<std::vector<int32_t>> by_len((size_t)max_len + 1);
@@ -1979,13 +1993,30 @@ int gfal_scorer_create_sharded(const int32_t *aln_off, const int32_t *aln_steps,
                 for (int t = 0; t < 4; ++t) key = (key << 16) | (t < m ? px[t] : 0u);
                 keyed[i] = Keyed{key, idx[i]};
             }
-            std::sort(keyed.begin(), keyed.end(), [&](const Keyed &x, const Keyed &y) {
+            auto less = [&](const Keyed &x, const Keyed &y) {
                 if (x.key != y.key) return x.key < y.key;
                 const uint16_t *px = ls + aln_off[x.idx], *py = ls + aln_off[y.idx];
                 for (int t = 4; t < m; ++t)
                     if (px[t] != py[t]) return px[t] < py[t];
                 return x.idx < y.idx;
-            });
+            };
+            if (keyed.size() < ((size_t)1 << 18) || std::thread::hardware_concurrency() < 4) {
+                std::sort(keyed.begin(), keyed.end(), less);
+            } else {      // a big bucket: four sorted quarters, merged pairwise
+                const size_t q = keyed.size() / 4;
+                auto part = [&](int k) { return keyed.begin() + (ptrdiff_t)(k == 4 ? keyed.size() : q * (size_t)k); };
+                std::thread t1([&] { std::sort(part(1), part(2), less); });
+                std::thread t2([&] { std::sort(part(2), part(3), less); });
+                std::thread t3([&] { std::sort(part(3), part(4), less); });
+                std::sort(part(0), part(1), less);
+                t1.join();
+                t2.join();
+                t3.join();
+                std::thread tm([&] { std::inplace_merge(part(2), part(3), part(4), less); });
+                std::inplace_merge(part(0), part(1), part(2), less);
+                tm.join();
+                std::inplace_merge(part(0), part(2), part(4), less);
+            }
             for (size_t i = 0; i < idx.size(); ++i) idx[i] = keyed[i].idx;
         };
         unsigned n_threads = std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency()));
@@ -2001,56 +2032,79 @@ int gfal_scorer_create_sharded(const int32_t *aln_off, const int32_t *aln_steps,
         worker();
         for (auto &t : pool) t.join();
     }
-    std::vector<uint16_t> item_steps;
-    std::vector<uint32_t> item_base;
+    mark("bucket + sort");
+    // item directory first (sequential, cheap), then the lanes are filled in
+    // parallel: every item writes its own ranges
+    struct ItemSrc {
+        const int32_t *idx;   // the item's alignments (original indices)
+        int cnt, m;
+    };
+    std::vector<ItemSrc> src;
+    std::vector<uint32_t> item_base, item_pbase;
     std::vector<uint16_t> item_len;
-    std::vector<uint32_t> item_pairs, item_pbase;
-    std::vector<int32_t> slot_orig;
-    item_steps.reserve((size_t)S / (size_t)n_shards + 64 * 64);
-    uint64_t global_item = 0;
+    uint64_t global_item = 0, n_u16 = 0, n_pairs = 0;
     int64_t own_aln = n_empty, own_steps = 0;
     for (int m = 1; m <= max_len; ++m) {
-        std::vector<int32_t> &idx = by_len[(size_t)m];
-        if (idx.empty()) continue;
-        const uint16_t *ls = local_steps.data();
+        const std::vector<int32_t> &idx = by_len[(size_t)m];
         for (size_t at = 0; at < idx.size(); at += WAVE) {
-            size_t cnt = std::min<size_t>(WAVE, idx.size() - at);
+            const size_t cnt = std::min<size_t>(WAVE, idx.size() - at);
             // shards are cut AFTER the global sort, item by item: a shard's items
             // are a subset of the unsharded ones (same lanes side by side), so the
             // scan kernel does on 1/n of the items exactly 1/n of the work
             if ((int32_t)(global_item++ % (uint64_t)n_shards) != shard_index) continue;
-            size_t base = item_steps.size();
-            item_base.push_back((uint32_t)(base / WAVE));
+            src.push_back(ItemSrc{idx.data() + at, (int)cnt, m});
+            item_base.push_back((uint32_t)(n_u16 / WAVE));
+            item_pbase.push_back((uint32_t)(n_pairs / WAVE));
             item_len.push_back((uint16_t)m);
-            item_steps.resize(base + (size_t)m * WAVE, (uint16_t)STEP_INVALID);
-            const size_t pbase = item_pairs.size();
-            const int K = m / 2;
-            item_pbase.push_back((uint32_t)(pbase / WAVE));
-            item_pairs.resize(pbase + (size_t)K * WAVE, 0xFFFFFFFFu);
-            for (size_t l = 0; l < WAVE; ++l) {
-                if (l < cnt) {
-                    const uint16_t *px = ls + aln_off[idx[at + l]];
-                    for (int t = 0; t < m; ++t)
-                        item_steps[base + (size_t)t * WAVE + l] = px[t];
-                    for (int k = 0; k < K; ++k)
-                        item_pairs[pbase + (size_t)k * WAVE + l] =
-                            (uint32_t)px[2 * k + 1] |
-                            ((2 * k + 2 < m) ? ((uint32_t)px[2 * k + 2] << 16) : 0u);
-                    slot_orig.push_back(idx[at + l]);
-                    for (int t = 0; t < m; ++t) ++hist[px[t] >> 1];
-                    ++own_aln;
-                    own_steps += m;
-                } else {
-                    slot_orig.push_back(-1);
-                }
-            }
+            n_u16 += (uint64_t)m * WAVE;
+            n_pairs += (uint64_t)(m / 2) * WAVE;
+            own_aln += (int64_t)cnt;
+            own_steps += (int64_t)cnt * m;
         }
     }
-    if (item_steps.size() / WAVE >= ((uint64_t)1 << 32) ||
-        item_base.size() >= ((size_t)1 << 25)) {
+    if (n_u16 / WAVE >= ((uint64_t)1 << 32) || src.size() >= ((size_t)1 << 25)) {
         set_err("shard too large for 32-bit item addressing");
         return GFAL_E_RANGE;
     }
+    std::vector<uint16_t> item_steps((size_t)n_u16, (uint16_t)STEP_INVALID);
+    std::vector<uint32_t> item_pairs((size_t)n_pairs, 0xFFFFFFFFu);
+    std::vector<int32_t> slot_orig(src.size() * WAVE, -1);
+    {
+        unsigned n_threads = std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency()));
+        if (const char *env = getenv("GFAL_CREATE_THREADS")) n_threads = (unsigned)std::max(1, atoi(env));
+        if (src.size() < 4096) n_threads = 1;
+        std::vector<std::vector<uint32_t>> hists(n_threads, std::vector<uint32_t>((size_t)n_local, 0));
+        const uint16_t *ls = local_steps.data();
+        auto fill = [&](unsigned tid) {
+            std::vector<uint32_t> &h = hists[tid];
+            const size_t lo = src.size() * tid / n_threads, hi = src.size() * (tid + 1) / n_threads;
+            for (size_t it = lo; it < hi; ++it) {
+                const ItemSrc &is = src[it];
+                const int m = is.m, K = m / 2;
+                uint16_t *steps = item_steps.data() + (size_t)item_base[it] * WAVE;
+                uint32_t *pairs = item_pairs.data() + (size_t)item_pbase[it] * WAVE;
+                for (int l = 0; l < is.cnt; ++l) {
+                    const uint16_t *px = ls + aln_off[is.idx[l]];
+                    for (int t = 0; t < m; ++t) {
+                        steps[(size_t)t * WAVE + l] = px[t];
+                        ++h[px[t] >> 1];
+                    }
+                    for (int k = 0; k < K; ++k)
+                        pairs[(size_t)k * WAVE + l] =
+                            (uint32_t)px[2 * k + 1] |
+                            ((2 * k + 2 < m) ? ((uint32_t)px[2 * k + 2] << 16) : 0u);
+                    slot_orig[it * WAVE + (size_t)l] = is.idx[l];
+                }
+            }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < n_threads; ++t) pool.emplace_back(fill, t);
+        fill(0);
+        for (auto &t : pool) t.join();
+        for (auto &h : hists)
+            for (size_t v = 0; v < h.size(); ++v) hist[v] += h[v];
+    }
+    mark("items");
 
     gfal_scorer *s = new (std::nothrow) gfal_scorer();
     if (!s) return GFAL_E_NOMEM;
@@ -2125,6 +2179,7 @@ int gfal_scorer_create_sharded(const int32_t *aln_off, const int32_t *aln_steps,
                          (size_t)row_scratch_words(max_len) * sizeof(uint32_t)));
 
 #undef CREATE_TRY
+    mark("device upload");
     *out = s;
     return GFAL_OK;
 }
