@@ -8,16 +8,20 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <climits>
+#include <condition_variable>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <iomanip>
 #include <iostream>
+#include <mutex>
 #include <set>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <unordered_set>
 #include <vector>
 
@@ -223,24 +227,86 @@ int run_eval_path(const Options &o, const Graph &g, const std::vector<GafRecord>
     if (!scorer.score(off, pst, false, bad, good)) return 1;              // :238
     std::vector<int32_t> fw, rc;
     if (!scorer.pair_scores(pst, fw, rc)) return 1;
-    for (size_t k = 0; k < recs.size(); ++k) {                            // :100-102
+    // One row per alignment (:100-102).  The scores come from the GPU; the gapped
+    // row text needs the traceback itself, which is rendered on the host -- for a
+    // 10 M-alignment GAF that is tens of GB of text, so blocks of alignments are
+    // rendered on all cores and written in order.
+    const size_t n_rec = recs.size();
+    const size_t block = 2048;
+    const size_t n_blocks = (n_rec + block - 1) / block;
+    unsigned n_threads = std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency()));
+    if (n_blocks < 4) n_threads = 1;
+    std::vector<std::string> text(n_blocks);
+    std::vector<char> ready(n_blocks, 0);
+    std::string failure;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::atomic<size_t> next_block{0};
+    size_t written = 0;                       // guarded by mu: blocks already printed
+    auto render = [&]() {
         std::vector<Step> B;
-        for (int32_t t = packed.off[k]; t < packed.off[k + 1]; ++t)
-            B.push_back({packed.steps[(size_t)t] >> 1, (packed.steps[(size_t)t] & 1) ? '-' : '+'});
-        const bool show_fw = fw[k] > rc[k];
-        if (!show_fw) {   // include/alignments.h:64-70
-            std::reverse(B.begin(), B.end());
-            for (auto &s : B) s.orientation = (s.orientation == '+') ? '-' : '+';
+        for (size_t blk = next_block++; blk < n_blocks; blk = next_block++) {
+            {   // stay at most 64 blocks ahead of the writer (memory)
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return blk < written + 64 || !failure.empty(); });
+                if (!failure.empty()) return;
+            }
+            std::string out;
+            const size_t hi = std::min(n_rec, (blk + 1) * block);
+            for (size_t k = blk * block; k < hi; ++k) {
+                B.clear();
+                for (int32_t t = packed.off[k]; t < packed.off[k + 1]; ++t)
+                    B.push_back({packed.steps[(size_t)t] >> 1, (packed.steps[(size_t)t] & 1) ? '-' : '+'});
+                const bool show_fw = fw[k] > rc[k];
+                if (!show_fw) {   // include/alignments.h:64-70
+                    std::reverse(B.begin(), B.end());
+                    for (auto &st : B) st.orientation = (st.orientation == '+') ? '-' : '+';
+                }
+                Rows rows = traceback_rows(path, B);
+                const int32_t best = std::max(fw[k], rc[k]);
+                if (rows.score != best) {
+                    std::lock_guard<std::mutex> lk(mu);
+                    if (failure.empty())
+                        failure = "device score " + std::to_string(best) + " != rendered score " +
+                                  std::to_string(rows.score) + " for " + recs[k].qname;
+                    cv.notify_all();
+                    return;
+                }
+                out += b_row(rows, g);
+                out += '\t';
+                out += recs[k].qname;
+                out += '\t';
+                out += std::to_string(best);
+                out += '\n';
+            }
+            std::lock_guard<std::mutex> lk(mu);
+            text[blk] = std::move(out);
+            ready[blk] = 1;
+            cv.notify_all();
         }
-        Rows rows = traceback_rows(path, B);
-        const int32_t best = std::max(fw[k], rc[k]);
-        if (rows.score != best) {
-            fprintf(stderr, "Error: device score %d != rendered score %d for %s\n", best,
-                    rows.score, recs[k].qname.c_str());
-            return 1;
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < n_threads; ++t) pool.emplace_back(render);
+    for (size_t blk = 0; blk < n_blocks; ++blk) {
+        std::string out;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return ready[blk] || !failure.empty(); });
+            if (!failure.empty()) break;
+            out = std::move(text[blk]);
+            text[blk].clear();
+            text[blk].shrink_to_fit();
+            written = blk + 1;
+            cv.notify_all();
         }
-        std::cout << b_row(rows, g) << '\t' << recs[k].qname << '\t' << best << std::endl;
+        std::cout.write(out.data(), (std::streamsize)out.size());
     }
+    for (auto &t : pool) t.join();
+    if (!failure.empty()) {
+        fprintf(stderr, "Error: %s\n", failure.c_str());
+        return 1;
+    }
+    std::cout.flush();
     const int32_t alt = (int32_t)bad[0] - (int32_t)good[0] - (int32_t)uniques;
     std::cout << bad[0] << "\t" << good[0] << "\t" << alt << "\t" << path.size() << "\t"
               << uniques << std::endl;                                     // :241

@@ -27,13 +27,25 @@ print("  %d path rows; best: %s" % (len(rows), "\t".join(rows[-1].split("\t")[:7
 if rows:
     best = rows[-1].split("\t")[7]
     t0 = time.time()
-    with open(d + "/evalpath.out", "w") as f:
-        q = subprocess.run([cli, "evalPath", "-f", d + "/g.gfa", "-g", d + "/a.gaf", "-p", best],
-                           stdout=f, stderr=subprocess.PIPE, text=True)
+    # the output is ~n x 11 bytes per alignment (94 GB for 10 M alignments and a
+    # 858-step path): counted and checksummed on the fly, not stored
+    q = subprocess.Popen([cli, "evalPath", "-f", d + "/g.gfa", "-g", d + "/a.gaf", "-p", best],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    n_bytes = n_lines = 0
+    last = b""
+    tail = b""
+    while True:
+        chunk = q.stdout.read(1 << 24)
+        if not chunk:
+            break
+        n_bytes += len(chunk)
+        n_lines += chunk.count(b"\n")
+        tail = (tail + chunk)[-400:]
+    err = q.stderr.read().decode()
+    rc = q.wait()
     dt = time.time() - t0
-    tail = subprocess.run(["tail", "-1", d + "/evalpath.out"], capture_output=True, text=True).stdout.strip()
-    n_lines = int(subprocess.run(["wc", "-l", d + "/evalpath.out"], capture_output=True, text=True).stdout.split()[0])
-    print("evalPath on the best path (%d steps): %.2f s, rc %d, %d output lines, summary: %s %s" % (
-        best.count(",") + 1, dt, q.returncode, n_lines, tail, q.stderr.strip()[-200:]))
+    summary = tail.decode(errors="replace").rstrip("\n").split("\n")[-1]
+    print("evalPath on the best path (%d steps): %.1f s, rc %d, %d lines, %.1f GB of rows, summary: %s %s" % (
+        best.count(",") + 1, dt, rc, n_lines, n_bytes / 1e9, summary, err.strip()[-200:]))
     srow = rows[-1].split("\t")
     print("  search row said bad %s good %s (filter on); evalPath counts every alignment (filter off)" % (srow[1], srow[2]))
