@@ -28,12 +28,12 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def cpu_baseline(t, budget_pairs=1.6e6):
+def cpu_baseline(t, budget_pairs=3.2e6):
     """Time the CPU oracle (port of the reference algorithm) on a bounded
-    sample of the SAME workload: 8 candidates spread over the length range
+    sample of the SAME workload: 16 candidates spread over the length range
     against the first alignments, sized for roughly 10-30 s on one core."""
     import oracle
-    n_paths = 8
+    n_paths = 16
     n_aln = int(min(t.N, budget_pairs // n_paths))
     order = np.argsort(np.diff(t.path_off), kind="stable")
     pick = order[np.linspace(0, t.P - 1, n_paths).astype(int)]
