@@ -119,3 +119,36 @@ def test_sample_of_full_batch_is_pair_exact(full, tangle):
     exp = oracle.evaluate_paths(off, st, poff, pst, True)
     for g, e in zip(got, exp):
         assert np.array_equal(g, e)
+
+
+def test_config5_size_shards_and_oracle_sample(gpu):
+    """BASELINE config 5's size (5 k nodes, 10 M alignments): the eight shards of
+    an 8-GPU run add up to the unsharded counters on a sample of the candidate
+    batch, `unaligned` matches the histogram, and four of the paths agree with
+    the oracle on the first 60 k alignments."""
+    t = synth.make("config5")
+    pick = np.linspace(0, t.P - 1, 96).astype(int)
+    poff, pst = csr([t.path_steps[t.path_off[k]:t.path_off[k + 1]] for k in pick])
+    with Scorer(t.aln_off, t.aln_steps, t.V) as sc:
+        bad, good, una = sc.evaluate_paths(poff, pst, True)
+    assert np.all(bad.astype(np.int64) + good <= t.N)
+    hist = np.bincount(t.aln_steps >> 1, minlength=t.V)
+    for k in (0, 50, 95):
+        nodes = np.unique(pst[poff[k]:poff[k + 1]] >> 1)
+        assert una[k] == t.S - hist[nodes].sum()
+    acc = [np.zeros(len(pick), np.uint64) for _ in range(3)]
+    for r in range(8):
+        with Scorer(t.aln_off, t.aln_steps, t.V, shard=(r, 8)) as sc:
+            for a, part in zip(acc, sc.evaluate_paths(poff, pst, True)):
+                a += part
+    assert np.array_equal(acc[0], bad) and np.array_equal(acc[1], good) and np.array_equal(acc[2], una)
+    n_sub = 60000
+    aoff = t.aln_off[:n_sub + 1]
+    ast = t.aln_steps[:aoff[-1]]
+    sub = [5, 40, 70, 95]
+    soff, sst = csr([pst[poff[k]:poff[k + 1]] for k in sub])
+    with Scorer(aoff, ast, t.V) as sc:
+        got = sc.evaluate_paths(soff, sst, True)
+    exp = oracle.evaluate_paths(aoff, ast, soff, sst, True)
+    for g, e in zip(got, exp):
+        assert np.array_equal(g, e)
