@@ -17,9 +17,12 @@
 //               counter per workgroup.  Pairs the cheap rules cannot decide
 //               go to a worklist.
 //   k_wl_*      counting sort of the worklist by (length class, path).
-//   k_dp_*      exact Needleman-Wunsch + traceback-exit propagation for the
-//               worklist (rare "start-overhang" pairs); rows in registers
-//               for alignments of up to 32 steps.
+//   k_dp_regs   exact Needleman-Wunsch + traceback-exit propagation for the
+//               worklist ("start-overhang" pairs): one pair per lane, rows in
+//               registers (alignments of up to 32 steps), only the table rows
+//               that can change the state; k_dp_long for longer alignments.
+//   k_dp_sys    the same for short worklists (search-sized batches), one table
+//               column per lane: the latency of a single fill decides there.
 //   k_pairs     the same exact DP for every alignment of one path, both
 //               orientations (evalPath's per-alignment scores).
 //
