@@ -55,6 +55,7 @@ constexpr int LDS_BUDGET = 80 * 1024;  // k_scan: two workgroups per CU (160 KiB
                                        // one 160 KiB workgroup (twice the tile, 4 waves
                                        // per SIMD) measured 19 % slower
 constexpr int LDS_MAX = 160 * 1024;
+constexpr int PREP_THREADS = 256;     // k_prep: four waves build one path image
 constexpr int DP_THREADS = 64;
 constexpr int DP_BLOCKS = 512;        // row-scratch kernels (k_dp_long, k_pairs)
 constexpr int DP_REG_BLOCKS = 4096, DP_SYS_BLOCKS = 2048;   // register-row kernels: 4 waves per SIMD
@@ -146,7 +147,7 @@ struct Items {
 // --------------------------------------------------------------------------
 // k_prep: candidate path -> lookup image (+ counter initialisation)
 // --------------------------------------------------------------------------
-__global__ __launch_bounds__(WAVE) void k_prep(
+__global__ __launch_bounds__(PREP_THREADS) void k_prep(
     const int32_t *__restrict__ path_off, const int32_t *__restrict__ path_steps,
     int n_paths, int64_t total_steps, int max_len,
     const int32_t *__restrict__ node_local, int n_nodes,
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(WAVE) void k_prep(
     uint32_t *head32 = reinterpret_cast<uint32_t *>(smem + L.total + L.nm);   // v2 chain heads
     // slot q of the image pool / of `counts` holds the q-th longest path
     const int q = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x;      // thread of the workgroup (four waves per path)
     if (q >= n_paths) return;
     const int p = order ? order[q] : q;
 
@@ -181,15 +182,15 @@ __global__ __launch_bounds__(WAVE) void k_prep(
     uint16_t *rstep = img + L.rstep_at();
     {   // 0xFFFF everywhere (32-bit stores), then the 32-bit chain entries
         uint32_t *img32 = reinterpret_cast<uint32_t *>(img);
-        for (int i = lane; i < L.total / 2; i += WAVE) img32[i] = 0xFFFFFFFFu;
+        for (int i = lane; i < L.total / 2; i += PREP_THREADS) img32[i] = 0xFFFFFFFFu;
         __syncthreads();
-        for (int i = lane; i < NEXT_CAP; i += WAVE)
+        for (int i = lane; i < NEXT_CAP; i += PREP_THREADS)
             next[i] = i == (int)(ENT_FOUND & ENT_POS) ? ENT_FOUND : ENT_NONE;
         __syncthreads();
     }
 
     bool id_ok = true;
-    for (int i = lane; i < n; i += WAVE) {
+    for (int i = lane; i < n; i += PREP_THREADS) {
         int32_t s = path_steps[off + i];
         bool other = (s & GFAL_STEP_OTHER) != 0;
         int32_t id = (s & ~GFAL_STEP_OTHER) >> 1;
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(WAVE) void k_prep(
     __syncthreads();
     // reverse complement (include/alignments.h:64-70), so that "rc(B) is a
     // subpath of the path" is searched as "B is a subpath of rc(path)"
-    for (int i = lane; i < n; i += WAVE) {
+    for (int i = lane; i < n; i += PREP_THREADS) {
         uint32_t code = step[n - 1 - i];
         rstep[i] = (uint16_t)(code == STEP_NOMATCH ? STEP_NOMATCH : (code ^ 1u));
     }
@@ -222,10 +223,10 @@ __global__ __launch_bounds__(WAVE) void k_prep(
     // chains; a node that only has such steps gets ENT_PRESENT (it still passes
     // the filter).  Exactly one position per node sees an empty head: it stands
     // for the node in the `unaligned` sum below.
-    for (int i = lane; i < L.v2; i += WAVE) head32[i] = ENT_NONE;
+    for (int i = lane; i < L.v2; i += PREP_THREADS) head32[i] = ENT_NONE;
     __syncthreads();
     uint32_t covered = 0;
-    for (int base = 0; base < n; base += WAVE) {
+    for (int base = 0; base < n; base += PREP_THREADS) {
         const int i = base + lane;
         const uint32_t lid = i < n ? (uint32_t)lids[i] : ENT_NONE;
         const uint32_t code = i < n ? (uint32_t)step[i] : STEP_NOMATCH;
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(WAVE) void k_prep(
         }
     }
     __syncthreads();
-    for (int base = 0; base < n; base += WAVE) {
+    for (int base = 0; base < n; base += PREP_THREADS) {
         const int i = base + lane;
         const uint32_t lid = i < n ? (uint32_t)lids[i] : ENT_NONE;
         if (lid != ENT_NONE && step[i] == STEP_NOMATCH) {
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(WAVE) void k_prep(
         }
     }
     __syncthreads();
-    for (int i = lane; i < L.v2; i += WAVE) first[i] = (uint16_t)head32[i];
+    for (int i = lane; i < L.v2; i += PREP_THREADS) first[i] = (uint16_t)head32[i];
     if (lane == 0) {
         img[L.len_at()] = (uint16_t)n;
         img[L.len_at() + 1] = 0;
@@ -257,11 +258,17 @@ __global__ __launch_bounds__(WAVE) void k_prep(
     __syncthreads();
 
     uint16_t *dst = images + (size_t)q * L.total;
-    for (int i = lane * 2; i < L.total; i += WAVE * 2)
+    for (int i = lane * 2; i < L.total; i += PREP_THREADS * 2)
         *reinterpret_cast<uint32_t *>(dst + i) =
             *reinterpret_cast<const uint32_t *>(img + i);
 
     for (int o = 32; o > 0; o >>= 1) covered += __shfl_down(covered, o, WAVE);
+    // across the waves: the chain heads are dead by now, their first word adds up
+    if (lane == 0) head32[0] = 0;
+    __syncthreads();
+    if ((lane & (WAVE - 1)) == 0 && covered) atomicAdd(&head32[0], covered);
+    __syncthreads();
+    covered = head32[0];
     if (lane == 0) {
         counts[q] = 0;
         counts[n_paths + q] = n_empty;
@@ -2268,7 +2275,7 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
         hipLaunchKernelGGL(k_len_scatter, dim3(p_blocks), dim3(256), 0, st, d_path_off,
                            (int)n_paths, s->d_len_bins, s->d_order);
     }
-    hipLaunchKernelGGL(k_prep, dim3((unsigned)n_paths), dim3(WAVE), prep_lds, st,
+    hipLaunchKernelGGL(k_prep, dim3((unsigned)n_paths), dim3(PREP_THREADS), prep_lds, st,
                        d_path_off, d_path_steps, (int)n_paths, total_steps,
                        (int)max_path_len, s->d_node_local, (int)s->n_nodes,
                        s->d_node_hist, (uint32_t)s->n_steps, s->n_empty, filter, L,
@@ -2536,7 +2543,7 @@ int gfal_scorer_pair_scores(gfal_scorer *s, const int32_t *path_steps, int32_t n
     HIP_TRY(hipMemsetAsync(s->d_status, 0, 2 * sizeof(uint32_t), s->stream));
     const size_t prep_lds = img_bytes + (size_t)L.nm * sizeof(uint16_t) +
                             (size_t)L.v2 * sizeof(uint32_t);
-    hipLaunchKernelGGL(k_prep, dim3(1), dim3(WAVE), prep_lds, s->stream, s->d_path_off,
+    hipLaunchKernelGGL(k_prep, dim3(1), dim3(PREP_THREADS), prep_lds, s->stream, s->d_path_off,
                        s->d_path_steps, 1, (int64_t)n, (int)n, s->d_node_local,
                        (int)s->n_nodes, s->d_node_hist, (uint32_t)s->n_steps,
                        s->n_empty, 0, L, nullptr, s->d_images, s->d_counts, s->d_status);
