@@ -1164,36 +1164,43 @@ __global__ __launch_bounds__(1024) void k_wl_offsets(const uint32_t *__restrict_
                                                       uint32_t *__restrict__ class_lo,
                                                       int n_paths)
 {
-    __shared__ uint32_t part[1024];
-    __shared__ uint32_t base;
+    // all classes side by side: one Hillis-Steele scan over the 1024 per-thread
+    // sums, five values wide
+    __shared__ uint32_t part[N_CLASSES][1024];
     const int tid = threadIdx.x;
-    if (tid == 0) base = 0;
-    __syncthreads();
+    uint32_t sum[N_CLASSES];
+#pragma unroll
     for (int c = 0; c < N_CLASSES; ++c) {
         const uint32_t *h = hist + (size_t)c * n_paths;
-        uint32_t sum = 0;
-        for (int p = tid; p < n_paths; p += 1024) sum += h[p];
-        part[tid] = sum;
+        uint32_t acc = 0;
+        for (int p = tid; p < n_paths; p += 1024) acc += h[p];
+        sum[c] = acc;
+        part[c][tid] = acc;
+    }
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        uint32_t v[N_CLASSES];
+#pragma unroll
+        for (int c = 0; c < N_CLASSES; ++c) v[c] = tid >= o ? part[c][tid - o] : 0u;
         __syncthreads();
-        for (int o = 1; o < 1024; o <<= 1) {      // Hillis-Steele inclusive scan
-            uint32_t v = tid >= o ? part[tid - o] : 0u;
-            __syncthreads();
-            part[tid] += v;
-            __syncthreads();
-        }
-        const uint32_t class_base = base;
-        uint32_t run = class_base + part[tid] - sum;
+#pragma unroll
+        for (int c = 0; c < N_CLASSES; ++c) part[c][tid] += v[c];
+        __syncthreads();
+    }
+    uint32_t class_base = 0;
+#pragma unroll
+    for (int c = 0; c < N_CLASSES; ++c) {
+        const uint32_t *h = hist + (size_t)c * n_paths;
+        uint32_t run = class_base + part[c][tid] - sum[c];
         for (int p = tid; p < n_paths; p += 1024) {
             offsets[(size_t)c * n_paths + p] = run;
             cursor[(size_t)c * n_paths + p] = 0;
             run += h[p];
         }
         if (tid == 0) class_lo[c] = class_base;
-        __syncthreads();
-        if (tid == 1023) base = class_base + part[1023];
-        __syncthreads();
+        class_base += part[c][1023];
     }
-    if (tid == 0) class_lo[N_CLASSES] = base;
+    if (tid == 0) class_lo[N_CLASSES] = class_base;
 }
 
 __global__ __launch_bounds__(256) void k_wl_scatter(
