@@ -1023,18 +1023,19 @@ __device__ __forceinline__ void dp_row_regs(uint32_t ai, const uint32_t (&b)[MC]
 // section 4, "steady state"; checked against the full fill in
 // tests/test_kernel_model.py).  So only the first m rows and the rows r..r+m
 // after every row r whose NODE occurs in B have to be computed -- a few dozen
-// of a 900-step path.  Doing more rows than that is always exact, so the window
-// is MC + 1 rows (a compile-time dilation) rather than m + 1.
+// of a 900-step path.  (Doing more rows than that would be exact too.)
 constexpr int ROW_WORDS = (GFAL_MAX_STEPS + 31) / 32;
 
 template <int MC>
-__device__ __forceinline__ unsigned long long dilate_rows(uint32_t bits)
+__device__ __forceinline__ unsigned long long dilate_rows(uint32_t bits, int m)
 {
-    unsigned long long v = bits;     // span 1 -> MC + 1 by doubling
+    // every marked row r -> rows r .. r + m, by doubling (span 1 -> m + 1); m is
+    // the lane's own alignment length (<= MC), so `by` is per lane
+    unsigned long long v = bits;
     int span = 1;
 #pragma unroll
-    for (int step = 1; span < MC + 1; step <<= 1) {
-        const int by = min(step, MC + 1 - span);
+    for (int step = 1; step <= MC; step <<= 1) {
+        const int by = max(0, min(step, m + 1 - span));
         v |= v << by;
         span += by;
     }
@@ -1095,7 +1096,7 @@ __device__ __forceinline__ int traceback_score_skip(const uint16_t *__restrict__
     }
     int block = -1;                      // current 32-row block of the path
     uint32_t todo = 0;                   // its rows still to compute
-    unsigned long long carry = (1ull << MC) - 1ull;   // rows 1..MC: the state is not steady yet
+    unsigned long long carry = (1ull << m) - 1ull;    // rows 1..m: the state is not steady yet
     bool done = n == 0;
     while (WAVE_ANY(!done)) {
         if (todo == 0 && !done) {
@@ -1103,7 +1104,7 @@ __device__ __forceinline__ int traceback_score_skip(const uint16_t *__restrict__
             if (block * 32 >= n) {
                 done = true;
             } else {
-                const unsigned long long rows = carry | dilate_rows<MC>(rowbits[block][lane]);
+                const unsigned long long rows = carry | dilate_rows<MC>(rowbits[block][lane], m);
                 todo = (uint32_t)rows;
                 carry = rows >> 32;
                 const int left = n - block * 32;
