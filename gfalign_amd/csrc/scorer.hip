@@ -56,6 +56,7 @@ constexpr int LDS_BUDGET = 80 * 1024;  // k_scan: two workgroups per CU (160 KiB
                                        // per SIMD) measured 19 % slower
 constexpr int LDS_MAX = 160 * 1024;
 constexpr int PREP_THREADS = 256;     // k_prep: four waves build one path image
+constexpr int N_CLASSES = 5, LONG_CLASS = 4;   // length classes of the DP kernels, see length_class()
 constexpr int DP_THREADS = 64;
 constexpr int DP_BLOCKS = 512;        // row-scratch kernels (k_dp_long, k_pairs)
 constexpr int DP_REG_BLOCKS = 4096, DP_SYS_BLOCKS = 2048;   // register-row kernels: 4 waves per SIMD
@@ -154,7 +155,8 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(
     const uint32_t *__restrict__ node_hist, uint32_t hist_total,
     uint32_t n_empty, int filter, ImageLayout L,
     const int32_t *__restrict__ order, uint16_t *__restrict__ images,
-    uint32_t *__restrict__ counts, uint32_t *__restrict__ status)
+    uint32_t *__restrict__ counts, uint32_t *__restrict__ status,
+    uint32_t *__restrict__ wl_hist)
 {
     extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
     uint16_t *img = smem;
@@ -165,6 +167,8 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(
     const int lane = threadIdx.x;      // thread of the workgroup (four waves per path)
     if (q >= n_paths) return;
     const int p = order ? order[q] : q;
+    // this slot's bins of the worklist histogram (k_scan counts into them)
+    if (wl_hist && lane < N_CLASSES) wl_hist[lane * n_paths + q] = 0;
 
     int64_t off = path_off[p];
     int64_t end = path_off[p + 1];
@@ -403,7 +407,6 @@ constexpr uint32_t WL_PATH_MASK = 0x3FFFFFFFu;
 
 // Length classes of the DP kernels (rows held in 4 / 8 / 16 / 32 registers, or
 // in LDS / HBM for longer alignments).
-constexpr int N_CLASSES = 5, LONG_CLASS = 4;
 __host__ __device__ __forceinline__ int length_class(int m)
 {
     return m <= 4 ? 0 : m <= 8 ? 1 : m <= 16 ? 2 : m <= 32 ? 3 : LONG_CLASS;
@@ -2258,9 +2261,10 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
     uint32_t *d_hist = s->d_wl_bins, *d_offsets = s->d_wl_bins + n_bins,
              *d_cursor = s->d_wl_bins + 2 * (size_t)n_bins,
              *d_class_lo = s->d_wl_bins + 3 * (size_t)n_bins;
-    const bool one_block_sort = n_paths <= 32768;   // k_len_sort_block also clears these
+    // the worklist histogram is cleared by k_prep (every path its own bins), the
+    // status words by k_len_sort_block
+    const bool one_block_sort = n_paths <= 32768;
     if (!one_block_sort) {
-        HIP_TRY(hipMemsetAsync(d_hist, 0, (size_t)n_bins * sizeof(uint32_t), st));
         HIP_TRY(hipMemsetAsync(s->d_status, 0, 4 * sizeof(uint32_t), st));
     }
     hipEvent_t *ev = s->ev[s->ev_calls % gfal_scorer::EV_RING];
@@ -2274,7 +2278,7 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
     d_counts = s->d_counts_slot;
     if (one_block_sort) {
         hipLaunchKernelGGL(k_len_sort_block, dim3(1), dim3(LEN_BINS), 0, st, d_path_off,
-                           (int)n_paths, s->d_order, d_hist, n_bins, s->d_status, 4);
+                           (int)n_paths, s->d_order, s->d_status, 4, nullptr, 0);
     } else {
         HIP_TRY(hipMemsetAsync(s->d_len_bins, 0, LEN_BINS * sizeof(uint32_t), st));
         hipLaunchKernelGGL(k_len_hist, dim3(p_blocks), dim3(256), 0, st, d_path_off,
@@ -2287,7 +2291,7 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
                        d_path_off, d_path_steps, (int)n_paths, total_steps,
                        (int)max_path_len, s->d_node_local, (int)s->n_nodes,
                        s->d_node_hist, (uint32_t)s->n_steps, s->n_empty, filter, L,
-                       s->d_order, s->d_images, d_counts, s->d_status);
+                       s->d_order, s->d_images, d_counts, s->d_status, d_hist);
     HIP_TRY(hipGetLastError());
     if (s->profiling) HIP_TRY(hipEventRecord(ev[1], st));
 
@@ -2554,7 +2558,7 @@ int gfal_scorer_pair_scores(gfal_scorer *s, const int32_t *path_steps, int32_t n
     hipLaunchKernelGGL(k_prep, dim3(1), dim3(PREP_THREADS), prep_lds, s->stream, s->d_path_off,
                        s->d_path_steps, 1, (int64_t)n, (int)n, s->d_node_local,
                        (int)s->n_nodes, s->d_node_hist, (uint32_t)s->n_steps,
-                       s->n_empty, 0, L, nullptr, s->d_images, s->d_counts, s->d_status);
+                       s->n_empty, 0, L, nullptr, s->d_images, s->d_counts, s->d_status, nullptr);
     HIP_TRY(hipGetLastError());
 
     // device results are indexed like the caller's alignments (all shards)
