@@ -1297,16 +1297,21 @@ __device__ __forceinline__ DpEntry load_entry(const DpArgs &a, uint32_t w, bool 
     return e;
 }
 
-// Which kernel family runs length class 2 (up to 16 columns) or the classes
-// from 3 up (17 and more): the wavefront kernels (k_dp_sys) while the class holds
+// Which kernel family runs a length class (the classes from 3 up count as one):
+// the wavefront kernels (k_dp_sys) while the class holds
 // few entries -- then the latency of one fill decides, and a column per lane has
 // the shorter one -- the one-pair-per-lane kernels (k_dp_regs / k_dp_long) when
 // it holds many.  Every kernel of both families evaluates this on the device.
 __device__ __forceinline__ bool wavefront_class(const DpArgs &a, uint32_t total, int cls)
 {
-    const uint32_t c2 = min(a.class_lo[2], total), c3 = min(a.class_lo[3], total);
-    const uint32_t n = cls == 2 ? c3 - c2 : total - c3;
-    return n <= (cls == 2 ? a.sys_limit : a.sys_limit / 2);
+    const uint32_t lo = min(a.class_lo[min(cls, 3)], total);
+    const uint32_t hi = cls >= 3 ? total : min(a.class_lo[cls + 1], total);
+    // measured crossovers (config 3, its 1/8 shard and search-sized batches): the
+    // 16-column wavefront stays ahead up to ~32 k entries, the 4- and 8-column
+    // ones up to ~8 k, the whole-wave one (an entry per wave) up to ~4 k
+    const uint32_t limit = cls >= 3 ? a.sys_limit / 2 : cls == 2 ? min(a.sys_limit, 0x3FFFFFFFu) * 4u
+                                                                 : a.sys_limit;
+    return hi - lo <= limit;
 }
 
 // Adds a wave's decisions to the per-path counters: two atomics per distinct
@@ -1345,9 +1350,7 @@ __global__ __launch_bounds__(DP_THREADS) void k_dp_regs(DpArgs a)
     __shared__ uint16_t path_lds[STAGED_PATHS][GFAL_MAX_STEPS + 8];
     if (*a.wl_count > a.wl_capacity) return;     // overflow: see k_wl_scatter
     const uint32_t total = *a.wl_count;
-    // short list: from 16 columns up the wavefront kernels have the lower latency
-    // (with few columns the skipped rows count for more, see k_dp_sys)
-    if (CLS >= 2 && wavefront_class(a, total, CLS)) return;
+    if (wavefront_class(a, total, CLS)) return;   // few entries: k_dp_sys has the lower latency
     uint32_t lo, hi;
     class_range(a.class_lo, CLS, total, lo, hi);
     const uint32_t n_threads = gridDim.x * DP_THREADS;
@@ -1459,63 +1462,133 @@ __device__ __forceinline__ void sys_step(int s, int j, int n, uint32_t b, int up
 template <int MC>
 __global__ __launch_bounds__(DP_THREADS) void k_dp_sys(DpArgs a)
 {
-    static_assert(MC == 16 || MC == 64, "group = DPP row, or the wave");
+    static_assert(MC == 4 || MC == 8 || MC == 16 || MC == 64, "group inside a DPP row, or the wave");
     constexpr int G = WAVE / MC;                          // lane groups (fills) per wave
     // MC < 64: an entry takes two neighbouring groups, one per orientation;
     // MC = 64: one entry per wave, the orientations one after the other
     constexpr int ENTRIES = MC == 64 ? 1 : G / 2;
     constexpr int PAD = MC;                               // reads of idle lanes stay inside
-    __shared__ uint16_t apath[G][GFAL_MAX_STEPS + 2 * PAD + 8];
+    // per entry (its two orientation groups write the same values)
+    __shared__ uint16_t apath[ENTRIES][GFAL_MAX_STEPS + 2 * PAD + 8];   // the entries' paths
+    __shared__ uint16_t alist[ENTRIES][GFAL_MAX_STEPS + 2 * PAD + 8];   // their steps at the rows to compute
+    __shared__ uint32_t rowmark[ENTRIES][ROW_WORDS + 2];  // rows whose node occurs in B
+    __shared__ uint32_t rowsel[ENTRIES][ROW_WORDS + 2];   // rows to compute
     if (*a.wl_count > a.wl_capacity) return;              // overflow: see k_wl_scatter
     const uint32_t total = *a.wl_count;
-    if (!wavefront_class(a, total, MC == 16 ? 2 : 3)) return;   // many entries: k_dp_regs / k_dp_long
-    // MC = 16: class 2; MC = 64: class 3 and the entries of the last class that
-    // fit (k_dp_long skips those on a short list); classes 0 and 1 always take
-    // k_dp_regs, whose row skipping beats the wavefront for few columns
-    constexpr int CLS = MC == 16 ? 2 : 3;
+    // MC = 4, 8, 16: classes 0, 1, 2; MC = 64: class 3 and the entries of the last
+    // class that fit (k_dp_long skips those on a short list)
+    constexpr int CLS = MC == 4 ? 0 : MC == 8 ? 1 : MC == 16 ? 2 : 3;
+    if (!wavefront_class(a, total, CLS)) return;          // many entries: k_dp_regs / k_dp_long
     const uint32_t lo = min(a.class_lo[CLS], total);
     const uint32_t hi = MC == 64 ? total : min(a.class_lo[CLS + 1], total);
     const int lane = threadIdx.x;
     const int c = lane % MC, g = lane / MC;
+    const int en = MC == 64 ? 0 : g / 2;                  // my entry of the wave
     const int j = c + 1;
     for (uint32_t w0 = lo + blockIdx.x * ENTRIES; w0 < hi; w0 += gridDim.x * ENTRIES) {
-        const uint32_t w = w0 + (MC == 64 ? 0 : g / 2);
+        const uint32_t w = w0 + en;
         const DpEntry e = load_entry(a, w, w < hi);
         const bool live = w < hi && e.m <= MC;
         // stage the groups' paths with the whole wave, all loads of a path in
         // flight at once; neighbouring groups usually share the path (the two
         // orientations of an entry always do) and then share the copy
         __syncthreads();
-        int my_row = g;
+        int my_row = en;
         {
+            constexpr int SPAN_LANES = MC == 64 ? 64 : 2 * MC;    // lanes of one entry
             uint32_t prev_p = 0xFFFFFFFFu;
             int prev_row = 0;
-            for (int gg = 0; gg < G; ++gg) {
-                const uint32_t p_gg = (uint32_t)__builtin_amdgcn_readlane((int)e.p, gg * MC);
-                const int n_gg = __builtin_amdgcn_readlane(live ? e.n : 0, gg * MC);
-                int row = gg;
-                if (n_gg > 0) {
-                    if (p_gg == prev_p) {
+            for (int ee = 0; ee < ENTRIES; ++ee) {
+                const uint32_t p_ee = (uint32_t)__builtin_amdgcn_readlane((int)e.p, ee * SPAN_LANES);
+                const int n_ee = __builtin_amdgcn_readlane(live ? e.n : 0, ee * SPAN_LANES);
+                int row = ee;
+                if (n_ee > 0) {
+                    if (p_ee == prev_p) {
                         row = prev_row;
                     } else {
-                        const uint16_t *src = a.images + (size_t)p_gg * a.L.total + a.L.step_at();
+                        const uint16_t *src = a.images + (size_t)p_ee * a.L.total + a.L.step_at();
                         constexpr int LOADS = (GFAL_MAX_STEPS + WAVE - 1) / WAVE;
                         uint16_t t[LOADS];
 #pragma unroll
                         for (int k = 0; k < LOADS; ++k)
-                            t[k] = (lane + k * WAVE < n_gg) ? src[lane + k * WAVE] : (uint16_t)0;
+                            t[k] = (lane + k * WAVE < n_ee) ? src[lane + k * WAVE] : (uint16_t)0;
 #pragma unroll
                         for (int k = 0; k < LOADS; ++k)
-                            if (lane + k * WAVE < n_gg) apath[gg][PAD + lane + k * WAVE] = t[k];
-                        prev_p = p_gg;
-                        prev_row = gg;
+                            if (lane + k * WAVE < n_ee) apath[ee][PAD + lane + k * WAVE] = t[k];
+                        prev_p = p_ee;
+                        prev_row = ee;
                     }
                 }
-                if (g == gg) my_row = row;
+                if (en == ee) my_row = row;
             }
         }
         __syncthreads();
-        const uint16_t *arow = apath[my_row] + PAD - 1 - c;    // arow[s] = step of row s - c
+        // Row skipping as in traceback_score_skip: only the first m rows and the
+        // rows r .. r + m after every row r whose node occurs in B change the
+        // state; the group compacts the path steps of those rows into alist[] and
+        // the wavefront runs over that list (a 900-step path and a 10-step
+        // alignment: ~150 steps instead of 900).  Windows of more than 32 rows
+        // (m > 31) do not fit the 64-bit dilation: those entries take every row.
+        const int m = e.m;
+        const bool skipping = m <= 31;
+        for (int w = c; w < ROW_WORDS + 2; w += MC) {
+            rowmark[en][w] = 0;
+            rowsel[en][w] = 0;
+        }
+        __syncthreads();
+        {   // mark: lane c walks the occurrence chain of B[c]'s node
+            const uint16_t *img = a.images + (size_t)e.p * a.L.total;
+            const uint16_t *first = img + a.L.first_at();
+            const uint32_t *next = reinterpret_cast<const uint32_t *>(img + a.L.next_at());
+            uint32_t cur = ENT_NONE;
+            if (live && skipping && c < m) cur = first[(uint32_t)e.bp[c * WAVE] >> 1];
+            while (WAVE_ANY(cur < ENT_FOUND)) {
+                const bool on = cur < ENT_FOUND;
+                const uint32_t pos = cur & ENT_POS;
+                const uint32_t nx = next[pos];      // always inside next[]
+                if (on) atomicOr(&rowmark[en][pos >> 5], 1u << (pos & 31u));
+                cur = on ? nx : ENT_NONE;
+            }
+        }
+        __syncthreads();
+        if (live && skipping) {
+            for (int w = c; w < ROW_WORDS; w += MC) {
+                const unsigned long long d = dilate_rows<32>(rowmark[en][w], m);
+                if ((uint32_t)d) atomicOr(&rowsel[en][w], (uint32_t)d);
+                if (d >> 32) atomicOr(&rowsel[en][w + 1], (uint32_t)(d >> 32));
+            }
+            if (c == 0) atomicOr(&rowsel[en][0], (1u << m) - 1u);     // rows 1..m
+        }
+        __syncthreads();
+        int n_c = 0;                                      // rows to compute (group-uniform)
+        {
+            const int n_full = live ? e.n : 0;
+            for (int w0r = 0; w0r < ROW_WORDS; w0r += MC) {
+                const int w = w0r + c;
+                uint32_t bits = 0;
+                if (w < ROW_WORDS) {
+                    bits = skipping ? rowsel[en][w] : 0xFFFFFFFFu;
+                    const int left = n_full - w * 32;
+                    bits = left <= 0 ? 0u : left >= 32 ? bits : (bits & ((1u << left) - 1u));
+                }
+                const int cnt = __builtin_popcount(bits);
+                int incl = cnt;                           // inclusive prefix inside the group
+#pragma unroll
+                for (int o = 1; o < MC; o <<= 1) {
+                    const int v = __shfl_up(incl, o, MC);
+                    if (c >= o) incl += v;
+                }
+                int off = n_c + incl - cnt;
+                n_c += __shfl(incl, MC - 1, MC);
+                while (bits) {
+                    const int bpos = __builtin_ctz(bits);
+                    bits &= bits - 1u;
+                    alist[en][PAD + off++] = apath[my_row][PAD + w * 32 + bpos];
+                }
+            }
+        }
+        __syncthreads();
+        const uint16_t *arow = alist[en] + PAD - 1 - c;        // arow[s] = step of listed row s - c
 
         bool good = false;
         for (int pass = 0; pass < (MC == 64 ? 2 : 1); ++pass) {
@@ -1524,7 +1597,7 @@ __global__ __launch_bounds__(DP_THREADS) void k_dp_sys(DpArgs a)
             // section 2): their group idles
             const bool run = live && (flip ? e.has_rc : e.has_fw);
             if (!WAVE_ANY(run)) continue;
-            const int n = run ? e.n : 0, m = e.m;
+            const int n = run ? n_c : 0;                  // the listed rows stand for the path
             uint32_t b = STEP_INVALID;
             if (run && c < m)
                 b = flip ? ((uint32_t)e.bp[(m - 1 - c) * WAVE] ^ 1u) : (uint32_t)e.bp[c * WAVE];
@@ -1546,7 +1619,7 @@ __global__ __launch_bounds__(DP_THREADS) void k_dp_sys(DpArgs a)
                 sys_step<MC>(s + 1, j, n, b, up_cost, arow, a_next, l_dp, l_x, h_dp, h_x, g_dp, g_x);
             }
             // lane m-1 of the group holds cell (n, m)
-            good |= run && c == m - 1 && l_dp == l_x;
+            good |= run && n > 0 && c == m - 1 && l_dp == l_x;
         }
         // the entry's lanes: both of its groups
         constexpr int SPAN = MC == 64 ? 64 : 2 * MC;
@@ -2379,10 +2452,13 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
         };
         // every kernel of both families is launched; the list length (known on
         // the device only) decides which family returns at once
+        hipLaunchKernelGGL(k_dp_sys<4>, dim3(DP_SYS_BLOCKS), dim3(DP_THREADS), 0, st, d);
         hipLaunchKernelGGL((k_dp_regs<4, 0>), dim3(DP_REG_BLOCKS), dim3(DP_THREADS), 0, st, d);
-        if (s->max_aln_len > 4)
-            hipLaunchKernelGGL((k_dp_regs<8, 1>), dim3(DP_REG_BLOCKS), dim3(DP_THREADS), 0,
-                               side(0), d);
+        if (s->max_aln_len > 4) {
+            hipStream_t s0 = side(0);
+            hipLaunchKernelGGL(k_dp_sys<8>, dim3(DP_SYS_BLOCKS), dim3(DP_THREADS), 0, s0, d);
+            hipLaunchKernelGGL((k_dp_regs<8, 1>), dim3(DP_REG_BLOCKS), dim3(DP_THREADS), 0, s0, d);
+        }
         if (s->max_aln_len > 8) {
             hipStream_t s1 = side(1);
             hipLaunchKernelGGL(k_dp_sys<16>, dim3(DP_SYS_BLOCKS), dim3(DP_THREADS), 0, s1, d);
