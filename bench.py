@@ -59,6 +59,41 @@ def cpu_baseline(t, budget_pairs=3.2e6):
     }, (pick, n_aln, bad, good, una)
 
 
+def cpu_fast(t, bad, good, una, n_paths=64):
+    """The kernels' own decision rule as a multi-threaded CPU program
+    (oracle/gfalign_fast.c, SURVEY.md 8(d) "cpu-fast"): 64 candidates spread over
+    the length range against ALL alignments, on one core and on all cores.  Its
+    counters are also compared with the HIP counters of the timed run."""
+    import oracle
+    order = np.argsort(np.diff(t.path_off), kind="stable")
+    pick = order[np.linspace(0, t.P - 1, n_paths).astype(int)]
+    paths = [t.path_steps[t.path_off[k]:t.path_off[k + 1]] for k in pick]
+    poff = np.zeros(n_paths + 1, np.int32)
+    poff[1:] = np.cumsum([len(p) for p in paths])
+    pst = np.concatenate(paths).astype(np.int32)
+    oracle.fast_lib()
+    # a GPU box gives one GPU's job a share of 16 host cores
+    cores = min(16, len(os.sched_getaffinity(0)))
+    res = {}
+    for label, thr, sel in (("one_core", 1, np.arange(2, n_paths, 4)), ("all_cores", cores, np.arange(n_paths))):
+        sub = [paths[k] for k in sel]
+        o = np.zeros(len(sub) + 1, np.int32)
+        o[1:] = np.cumsum([len(p) for p in sub])
+        st = np.concatenate(sub).astype(np.int32)
+        t0 = time.perf_counter()
+        b, g, u = oracle.fast_evaluate_paths(t.aln_off, t.aln_steps, o, st, True, threads=thr)
+        dt = time.perf_counter() - t0
+        res[label] = len(sub) / dt
+        if not (np.array_equal(b, bad[pick[sel]]) and np.array_equal(g, good[pick[sel]])
+                and np.array_equal(u, una[pick[sel]])):
+            sys.exit("PARITY FAILURE: HIP counters differ from oracle/gfalign_fast.c")
+    return {"value": res["all_cores"], "unit": "paths/s", "cores": cores,
+            "value_one_core": res["one_core"], "kind": "port-fast",
+            "sample": "oracle/gfalign_fast.c (filter bitmap, occurrence lists, overhang test, DP only "
+                      "where needed; OpenMP over blocks of alignments): %d candidates (length "
+                      "quantiles) x all %d alignments of %s; every fourth of them on one core" % (n_paths, t.N, t.name)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -221,6 +256,10 @@ def main():
                     and np.array_equal(gu, euna)):
                 sys.exit("PARITY FAILURE: HIP counters differ from the oracle on the sample")
             out["config"]["parity_sample"] = "bit-exact vs oracle on the cpu_baseline sample"
+            # an honest CPU competitor next to the reference-faithful baseline; also a
+            # second checker, on full-length alignment sets
+            out["cpu_fast"] = cpu_fast(t, bad, good, una)
+            out["config"]["parity_sample"] += " and vs oracle/gfalign_fast.c on 64 paths x all alignments"
         print(json.dumps(out))
     sc.close()
     if world > 1:

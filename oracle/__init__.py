@@ -86,3 +86,44 @@ def pair_scores(aln_off, aln_steps, path_steps):
     if rc:
         raise ValueError("oracle rejected the input (status %d)" % rc)
     return fw, rv
+
+
+# ---- the kernels' decision rule as a multi-threaded CPU program (gfalign_fast.c) ----
+_FAST_PATH = os.path.join(_HERE, "libgfalign_fast.so")
+_fast = None
+
+
+def fast_lib():
+    global _fast
+    if _fast is None:
+        src = os.path.join(_HERE, "gfalign_fast.c")
+        if not os.path.exists(_FAST_PATH) or os.path.getmtime(_FAST_PATH) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", _HERE, "-s", "libgfalign_fast.so"])
+        L = ctypes.CDLL(_FAST_PATH)
+        i32p = ctypes.POINTER(ctypes.c_int32)
+        u32p = ctypes.POINTER(ctypes.c_uint32)
+        L.gfo_fast_evaluate_paths_packed.restype = ctypes.c_int
+        L.gfo_fast_evaluate_paths_packed.argtypes = [
+            i32p, i32p, ctypes.c_int64, i32p, i32p, ctypes.c_int32, ctypes.c_int, ctypes.c_int,
+            u32p, u32p, u32p]
+        _fast = L
+    return _fast
+
+
+def fast_evaluate_paths(aln_off, aln_steps, path_off, path_steps, filter=True, threads=0):
+    """Same result as evaluate_paths(), computed with the kernels' decision rule
+    on `threads` host cores (0 = all)."""
+    aln_off, aln_steps = _i32(aln_off), _i32(aln_steps)
+    path_off, path_steps = _i32(path_off), _i32(path_steps)
+    n_aln, n_paths = len(aln_off) - 1, len(path_off) - 1
+    bad = np.zeros(n_paths, np.uint32)
+    good = np.zeros(n_paths, np.uint32)
+    una = np.zeros(n_paths, np.uint32)
+    rc = fast_lib().gfo_fast_evaluate_paths_packed(
+        _p(aln_off, ctypes.c_int32), _p(aln_steps, ctypes.c_int32), n_aln,
+        _p(path_off, ctypes.c_int32), _p(path_steps, ctypes.c_int32), n_paths,
+        int(bool(filter)), int(threads), _p(bad, ctypes.c_uint32), _p(good, ctypes.c_uint32),
+        _p(una, ctypes.c_uint32))
+    if rc:
+        raise ValueError("fast CPU scorer rejected the input (status %d)" % rc)
+    return bad, good, una
