@@ -152,3 +152,18 @@ def test_config5_size_shards_and_oracle_sample(gpu):
     exp = oracle.evaluate_paths(aoff, ast, soff, sst, True)
     for g, e in zip(got, exp):
         assert np.array_equal(g, e)
+
+
+def test_full_size_counters_equal_the_fast_cpu_checker(full, tangle):
+    """Every fourth path of the config-3 batch against ALL 1 M alignments, on the
+    CPU with oracle/gfalign_fast.c (pinned to the oracle by
+    tests/test_oracle_fast.py): the HIP counters at the full BASELINE size, bit
+    for bit -- not a property, the numbers themselves."""
+    _, (bad, good, una) = full
+    t = tangle
+    pick = np.arange(0, t.P, 4)
+    poff, pst = csr([t.path_steps[t.path_off[k]:t.path_off[k + 1]] for k in pick])
+    eb, eg, eu = oracle.fast_evaluate_paths(t.aln_off, t.aln_steps, poff, pst, True, threads=16)
+    assert np.array_equal(bad[pick], eb)
+    assert np.array_equal(good[pick], eg)
+    assert np.array_equal(una[pick], eu)
