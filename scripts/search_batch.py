@@ -64,8 +64,13 @@ def main():
         i = sc.info()
         print("%s search batch P=%d: %.2f ms per batch (%.0f paths/s); scan %.2f ms, sort+dp %.2f ms, dp pairs %d (%.0f per path)" % (
             cfg, P, wall * 1e3, P / wall, i["scan_ms"], i["dp_ms"], i["dp_pairs"], i["dp_pairs"] / P))
-    # parity on a sample (oracle, CPU): 6 paths x 50k alignments
+    # parity: every path of the batch against all alignments with the fast CPU
+    # checker (oracle/gfalign_fast.c, itself pinned to the oracle), and a small
+    # sample with the oracle proper
     import oracle
+    eb, eg, eu = oracle.fast_evaluate_paths(t.aln_off, t.aln_steps, off, steps, True, threads=16)
+    ok = np.array_equal(bad, eb) and np.array_equal(good, eg) and np.array_equal(una, eu)
+    print("parity, all %d paths x %d alignments vs oracle/gfalign_fast.c: %s" % (P, t.N, "OK" if ok else "MISMATCH"))
     pick = np.linspace(0, P - 1, 6).astype(int)
     soff = [0]; sst = []
     for p in pick:
@@ -75,8 +80,9 @@ def main():
     with Scorer(a_off, a_st, t.V) as sc:
         got = sc.evaluate_paths(np.asarray(soff, np.int32), np.concatenate(sst).astype(np.int32), True)
     exp = oracle.evaluate_paths(a_off, a_st, np.asarray(soff, np.int32), np.concatenate(sst).astype(np.int32), True)
-    ok = all(np.array_equal(g, e) for g, e in zip(got, exp))
-    print("oracle parity on 6 paths x %d alignments: %s" % (n_sub, "OK" if ok else "MISMATCH"))
+    ok2 = all(np.array_equal(g, e) for g, e in zip(got, exp))
+    print("oracle parity on 6 paths x %d alignments: %s" % (n_sub, "OK" if ok2 else "MISMATCH"))
+    ok = ok and ok2
     return 0 if ok else 1
 
 
