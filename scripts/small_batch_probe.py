@@ -11,7 +11,8 @@ sizes = [int(x) for x in (sys.argv[2].split(",") if len(sys.argv) > 2 else "8,32
 t = synth.make(cfg)
 rng = np.random.default_rng(5)
 with Scorer(t.aln_off, t.aln_steps, t.V) as sc:
-    sc.set_profiling(True)
+    prof = not os.environ.get("NOPROF")     # device phases need events; graphs are off then
+    sc.set_profiling(prof)
     P = len(t.path_off) - 1
     for n in sizes:
         pick = np.sort(rng.choice(P, n, replace=False))
@@ -22,9 +23,9 @@ with Scorer(t.aln_off, t.aln_steps, t.V) as sc:
         off = np.asarray(off, np.int32); steps = np.concatenate(steps).astype(np.int32)
         for _ in range(3):
             sc.evaluate_paths(off, steps, True)
-        sc.set_profiling(False); sc.set_profiling(True)
+        sc.set_profiling(False); sc.set_profiling(prof)
         t0 = time.perf_counter()
-        reps = 20
+        reps = 200 if not prof else 20
         for _ in range(reps):
             sc.evaluate_paths(off, steps, True)
         wall = (time.perf_counter() - t0) / reps * 1e3

@@ -298,6 +298,22 @@ def test_more_than_32k_paths_in_one_batch(gpu):
     assert np.array_equal(una[sample], eu)
 
 
+def test_graph_replay_gives_the_same_counters(gpu, monkeypatch):
+    """GFAL_GRAPHS=1: the blocking call captures its launches into a HIP graph and
+    updates the executable from call to call (batch shapes change)."""
+    rnd = random.Random(71)
+    alns, paths = walk_case(rnd, 25, 150, 900, 60, 14)
+    aoff, ast = csr(alns)
+    monkeypatch.setenv("GFAL_GRAPHS", "1")
+    with Scorer(aoff, ast, 32) as sc:
+        for lo, hi in ((0, 7), (7, 40), (3, 4), (0, 60), (10, 11)):
+            poff, pst = csr(paths[lo:hi])
+            got = sc.evaluate_paths(poff, pst, True)
+            exp = oracle.evaluate_paths(aoff, ast, poff, pst, True)
+            for g, e in zip(got, exp):
+                assert np.array_equal(g, e)
+
+
 def test_worklist_overflow_splits_the_batch(gpu, monkeypatch):
     """More exact-DP pairs than the worklist holds: the blocking API halves the
     batch until every piece fits (a single path always does)."""
