@@ -11,12 +11,15 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
 #include <iostream>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <set>
 #include <string>
 #include <thread>
@@ -162,6 +165,12 @@ class PathScorer {
 public:
     ~PathScorer()
     {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : workers_) t.join();
         for (gfal_scorer *h : shards_)
             if (h) gfal_scorer_destroy(h);
     }
@@ -213,15 +222,29 @@ public:
         std::vector<std::vector<uint32_t>> pb(D, std::vector<uint32_t>(P)), pg(D, std::vector<uint32_t>(P));
         std::vector<int> rcs(D, GFAL_OK);
         std::vector<std::string> errs(D);
-        auto work = [&](size_t d) {
+        std::function<void(size_t)> work = [&](size_t d) {
             rcs[d] = gfal_scorer_score(shards_[d], off.data(), steps.data(), (int32_t)P,
                                        filter ? 1 : 0, pb[d].data(), pg[d].data(), nullptr);
             if (rcs[d] != GFAL_OK) errs[d] = gfal_last_error();
         };
-        std::vector<std::thread> threads;
-        for (size_t d = 1; d < D; ++d) threads.emplace_back(work, d);
+        // one persistent worker per further device (a search makes thousands of
+        // calls: no thread start-up per batch); this thread takes device 0
+        if (workers_.empty() && D > 1) start_workers(D);
+        if (D > 1) {
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                job_ = &work;
+                pending_ = D - 1;
+                ++generation_;
+            }
+            cv_.notify_all();
+        }
         work(0);
-        for (auto &t : threads) t.join();
+        if (D > 1) {
+            std::unique_lock<std::mutex> lk(mu_);
+            done_cv_.wait(lk, [&] { return pending_ == 0; });
+            job_ = nullptr;
+        }
         for (size_t d = 0; d < D; ++d) {
             if (rcs[d] != GFAL_OK) {
                 fprintf(stderr, "Error: scorer: %s (%s)\n", gfal_strerror(rcs[d]), errs[d].c_str());
@@ -257,7 +280,38 @@ public:
     size_t n_shards() const { return shards_.size(); }
 
 private:
+    void start_workers(size_t n_devices)
+    {
+        for (size_t d = 1; d < n_devices; ++d)
+            workers_.emplace_back([this, d] {
+                uint64_t seen = 0;
+                while (true) {
+                    std::function<void(size_t)> *job;
+                    {
+                        std::unique_lock<std::mutex> lk(mu_);
+                        cv_.wait(lk, [&] { return stop_ || generation_ != seen; });
+                        if (stop_) return;
+                        seen = generation_;
+                        job = job_;
+                    }
+                    (*job)(d);
+                    {
+                        std::lock_guard<std::mutex> lk(mu_);
+                        --pending_;
+                    }
+                    done_cv_.notify_one();
+                }
+            });
+    }
+
     std::vector<gfal_scorer *> shards_;
+    std::vector<std::thread> workers_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_cv_;
+    std::function<void(size_t)> *job_ = nullptr;
+    size_t pending_ = 0;
+    uint64_t generation_ = 0;
+    bool stop_ = false;
     int64_t n_aln_ = 0;
     uint64_t dp_pairs_ = 0;
 };
