@@ -143,7 +143,16 @@ struct Items {
     const uint32_t *pairs;
     const uint32_t *pbase;  // per item, in units of 64 uint32
     int n_items;
+    // per item: a local node id that occurs in EVERY alignment of the item
+    // (content-sorted items nearly always have one: their first node), or
+    // NO_COMMON_NODE.  If no path of a tile carries it, every lane fails the
+    // filter for every tile path and the item is skipped for that tile without
+    // loading a step -- 44 % of the (item, tile) visits of the config-3 batch
+    const uint32_t *common;
+    // {base, pbase, common, len} of every item in one 16-byte load (k_scan)
+    const uint4 *hdr;
 };
+constexpr uint32_t NO_COMMON_NODE = 0xFFFFFFFFu;
 
 // --------------------------------------------------------------------------
 // k_prep: candidate path -> lookup image (+ counter initialisation)
@@ -856,11 +865,19 @@ __global__ __launch_bounds__(SCAN_THREADS, 6) void k_scan(ScanArgs a)
     // were measured 7 % slower: s_load shares the lgkm counter with the LDS reads)
     for (int it = chunk + wave * a.n_chunks; it < a.items.n_items;
          it += SCAN_WAVES * a.n_chunks) {
-        const int M = __builtin_amdgcn_readfirstlane((int)a.items.len[it]);
-        const uint16_t *bp =
-            a.items.steps + (size_t)a.items.base[it] * WAVE + lane;
+        // the item header in one load, then the decisions
+        const uint4 hdr = a.items.hdr[it];
+        const uint32_t base_v = hdr.x, pbase_v = hdr.y, common_v = hdr.z, len_v = hdr.w;
+        if (a.filter) {
+            const uint32_t common = (uint32_t)__builtin_amdgcn_readfirstlane((int)common_v);
+            if (common != NO_COMMON_NODE &&
+                __builtin_amdgcn_readfirstlane((int)tv.nodemask[common]) == 0)
+                continue;
+        }
+        const int M = __builtin_amdgcn_readfirstlane((int)len_v);
+        const uint16_t *bp = a.items.steps + (size_t)base_v * WAVE + lane;
         const uint32_t slot = (uint32_t)it * WAVE + lane;
-        const uint32_t *pp = a.items.pairs + (size_t)a.items.pbase[it] * WAVE + lane;
+        const uint32_t *pp = a.items.pairs + (size_t)pbase_v * WAVE + lane;
         if (M > 2 * MAX_REG_K + 1) {
             scan_item_long(a, tv, bp, M, lane, slot, wc);
             continue;
@@ -1714,6 +1731,8 @@ struct gfal_scorer {
     uint16_t *d_item_len = nullptr;
     uint32_t *d_item_pairs = nullptr;
     uint32_t *d_item_pbase = nullptr;
+    uint32_t *d_item_common = nullptr;   // Items::common
+    uint4 *d_item_hdr = nullptr;         // Items::hdr
     int32_t *d_slot_orig = nullptr;    // [n_items*64] original index or -1
     uint32_t *d_status = nullptr;      // [4]: status word, worklist count, 2 debug words
     unsigned long long *d_worklist = nullptr;   // as pushed by k_scan
@@ -1804,7 +1823,7 @@ void free_scorer(gfal_scorer *s)
 {
     if (!s) return;
     (void)hipSetDevice(s->device);
-    void *bufs[] = {s->d_item_pairs, s->d_item_pbase, s->d_len_bins, s->d_order,
+    void *bufs[] = {s->d_item_pairs, s->d_item_pbase, s->d_item_common, s->d_item_hdr, s->d_len_bins, s->d_order,
                     s->d_counts_slot,
                     s->d_node_local, s->d_node_hist, s->d_item_steps, s->d_item_base,
                     s->d_item_len,   s->d_slot_orig, s->d_status,     s->d_worklist,
@@ -2170,6 +2189,7 @@ int gfal_scorer_create_sharded(const int32_t *aln_off, const int32_t *aln_steps,
     std::vector<uint16_t> item_steps((size_t)n_u16, (uint16_t)STEP_INVALID);
     std::vector<uint32_t> item_pairs((size_t)n_pairs, 0xFFFFFFFFu);
     std::vector<int32_t> slot_orig(src.size() * WAVE, -1);
+    std::vector<uint32_t> item_common(src.size(), NO_COMMON_NODE);
     {
         unsigned n_threads = std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency()));
         if (const char *env = getenv("GFAL_CREATE_THREADS")) n_threads = (unsigned)std::max(1, atoi(env));
@@ -2195,6 +2215,19 @@ int gfal_scorer_create_sharded(const int32_t *aln_off, const int32_t *aln_steps,
                             (uint32_t)px[2 * k + 1] |
                             ((2 * k + 2 < m) ? ((uint32_t)px[2 * k + 2] << 16) : 0u);
                     slot_orig[it * WAVE + (size_t)l] = is.idx[l];
+                }
+                // a node every lane has: try the nodes of lane 0 in order
+                const uint16_t *p0 = ls + aln_off[is.idx[0]];
+                for (int t = 0; t < m && item_common[it] == NO_COMMON_NODE; ++t) {
+                    const uint32_t node = p0[t] >> 1;
+                    bool everywhere = true;
+                    for (int l = 1; l < is.cnt && everywhere; ++l) {
+                        const uint16_t *px = ls + aln_off[is.idx[l]];
+                        bool has = false;
+                        for (int u = 0; u < m && !has; ++u) has = (uint32_t)(px[u] >> 1) == node;
+                        everywhere = has;
+                    }
+                    if (everywhere) item_common[it] = node;
                 }
             }
         };
@@ -2262,6 +2295,13 @@ int gfal_scorer_create_sharded(const int32_t *aln_off, const int32_t *aln_steps,
     if ((rc = dev_upload(&s->d_item_len, item_len))) return fail(rc);
     if ((rc = dev_upload(&s->d_item_pairs, item_pairs))) return fail(rc);
     if ((rc = dev_upload(&s->d_item_pbase, item_pbase))) return fail(rc);
+    if ((rc = dev_upload(&s->d_item_common, item_common))) return fail(rc);
+    {
+        std::vector<uint4> item_hdr(src.size());
+        for (size_t it = 0; it < src.size(); ++it)
+            item_hdr[it] = make_uint4(item_base[it], item_pbase[it], item_common[it], item_len[it]);
+        if ((rc = dev_upload(&s->d_item_hdr, item_hdr))) return fail(rc);
+    }
     if ((rc = dev_upload(&s->d_slot_orig, slot_orig))) return fail(rc);
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_len_bins),
                          3 * LEN_BINS * sizeof(uint32_t)));
@@ -2391,7 +2431,7 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
     if (s->n_items > 0) {
         ScanArgs a;
         a.items = Items{s->d_item_steps, s->d_item_base, s->d_item_len, s->d_item_pairs,
-                        s->d_item_pbase, s->n_items};
+                        s->d_item_pbase, s->n_items, s->d_item_common, s->d_item_hdr};
         a.images = s->d_images;
         a.L = L;
         a.n_paths = n_paths;
@@ -2715,7 +2755,7 @@ int gfal_scorer_pair_scores(gfal_scorer *s, const int32_t *path_steps, int32_t n
                        (long long)n_in, 0);
     if (s->n_items > 0) {
         Items items{s->d_item_steps, s->d_item_base, s->d_item_len, s->d_item_pairs,
-                    s->d_item_pbase, s->n_items};
+                    s->d_item_pbase, s->n_items, s->d_item_common, s->d_item_hdr};
         if (dp_rows_fit_lds(s->max_aln_len))
             hipLaunchKernelGGL(k_pairs<true>, dim3(DP_BLOCKS), dim3(DP_THREADS),
                                dp_lds_bytes(s->max_aln_len), s->stream, items,
