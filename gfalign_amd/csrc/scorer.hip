@@ -874,6 +874,12 @@ __global__ __launch_bounds__(SCAN_THREADS, 6) void k_scan(ScanArgs a)
         const uint4 hdr = mine ? a.items.hdr[my_it] : make_uint4(0u, 0u, NO_COMMON_NODE, 0u);
         bool keep = mine;
         if (a.filter && mine && hdr.z != NO_COMMON_NODE) keep = tv.nodemask[hdr.z] != 0u;
+#if defined(GFAL_ABLATE) && GFAL_ABLATE == 7      // probe: (item, tile) visits and how many the common node rejects
+        if (lane == 0) {
+            atomicAdd(a.status + 3, (uint32_t)__builtin_popcountll(WAVE_MASK(mine)));
+            atomicAdd(a.status + 2, (uint32_t)__builtin_popcountll(WAVE_MASK(mine && !keep)));
+        }
+#endif
         for (lanemask todo = WAVE_MASK(keep); todo != 0; todo &= todo - 1) {
         const int src = __builtin_ctzll(todo);
         const int it = it0 + src * item_stride;
@@ -2819,6 +2825,9 @@ int gfal_scorer_get_info(gfal_scorer *s, gfal_info *out)
         out->dp_pairs = host[1];
 #if defined(GFAL_ABLATE) && GFAL_ABLATE == 4
         fprintf(stderr, "chain-loop iterations %u, with a wave-uniform entry %u\n", host[2], host[3]);
+#endif
+#if defined(GFAL_ABLATE) && GFAL_ABLATE == 7
+        fprintf(stderr, "(item, tile) visits %u, rejected through the common node %u\n", host[3], host[2]);
 #endif
         if (s->profiling && s->ev_calls > 0) {
             const int n = std::min(s->ev_calls, (int)gfal_scorer::EV_RING);
