@@ -147,7 +147,7 @@ struct Items {
     // (content-sorted items nearly always have one: their first node), or
     // NO_COMMON_NODE.  If no path of a tile carries it, every lane fails the
     // filter for every tile path and the item is skipped for that tile without
-    // loading a step -- 44 % of the (item, tile) visits of the config-3 batch
+    // loading a step -- a third of the (item, tile) visits of the config-3 batch
     const uint32_t *common;
     // {base, pbase, common, len} of every item in one 16-byte load (k_scan)
     const uint4 *hdr;
