@@ -143,9 +143,9 @@ struct Items {
     const uint32_t *pairs;
     const uint32_t *pbase;  // per item, in units of 64 uint32
     int n_items;
-    // per item: a local node id that occurs in EVERY alignment of the item
-    // (content-sorted items nearly always have one: their first node), or
-    // NO_COMMON_NODE.  If no path of a tile carries it, every lane fails the
+    // per item: two local node ids (16 bits each; possibly the same) that occur in
+    // EVERY alignment of the item (content-sorted items nearly always have some:
+    // their first nodes), or NO_COMMON_NODE.  If no path of a tile carries both, every lane fails the
     // filter for every tile path and the item is skipped for that tile without
     // loading a step -- a third of the (item, tile) visits of the config-3 batch
     const uint32_t *common;
@@ -873,7 +873,8 @@ __global__ __launch_bounds__(SCAN_THREADS, 6) void k_scan(ScanArgs a)
         const bool mine = my_it < a.items.n_items;
         const uint4 hdr = mine ? a.items.hdr[my_it] : make_uint4(0u, 0u, NO_COMMON_NODE, 0u);
         bool keep = mine;
-        if (a.filter && mine && hdr.z != NO_COMMON_NODE) keep = tv.nodemask[hdr.z] != 0u;
+        if (a.filter && mine && hdr.z != NO_COMMON_NODE)     // a tile path must carry both
+            keep = (tv.nodemask[hdr.z & 0xFFFFu] & tv.nodemask[hdr.z >> 16]) != 0u;
 #if defined(GFAL_ABLATE) && GFAL_ABLATE == 7      // probe: (item, tile) visits and how many the common node rejects
         if (lane == 0) {
             atomicAdd(a.status + 3, (uint32_t)__builtin_popcountll(WAVE_MASK(mine)));
@@ -2228,10 +2229,13 @@ int gfal_scorer_create_sharded(const int32_t *aln_off, const int32_t *aln_steps,
                             ((2 * k + 2 < m) ? ((uint32_t)px[2 * k + 2] << 16) : 0u);
                     slot_orig[it * WAVE + (size_t)l] = is.idx[l];
                 }
-                // a node every lane has: try the nodes of lane 0 in order
+                // nodes every lane has: the first and the last such node of lane 0
+                // (two 16-bit halves; NO_COMMON_NODE if there is none)
                 const uint16_t *p0 = ls + aln_off[is.idx[0]];
-                for (int t = 0; t < m && item_common[it] == NO_COMMON_NODE; ++t) {
+                uint32_t first_c = 0xFFFFu, last_c = 0xFFFFu;
+                for (int t = 0; t < m; ++t) {
                     const uint32_t node = p0[t] >> 1;
+                    if (node == first_c || node == last_c) continue;
                     bool everywhere = true;
                     for (int l = 1; l < is.cnt && everywhere; ++l) {
                         const uint16_t *px = ls + aln_off[is.idx[l]];
@@ -2239,8 +2243,12 @@ int gfal_scorer_create_sharded(const int32_t *aln_off, const int32_t *aln_steps,
                         for (int u = 0; u < m && !has; ++u) has = (uint32_t)(px[u] >> 1) == node;
                         everywhere = has;
                     }
-                    if (everywhere) item_common[it] = node;
+                    if (everywhere) {
+                        if (first_c == 0xFFFFu) first_c = node;
+                        last_c = node;
+                    }
                 }
+                item_common[it] = first_c == 0xFFFFu ? NO_COMMON_NODE : (first_c | (last_c << 16));
             }
         };
         std::vector<std::thread> pool;
