@@ -2538,12 +2538,13 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
         }
         if (s->max_aln_len > 8) {
             hipStream_t s1 = side(1);
-            hipLaunchKernelGGL(k_dp_sys<16>, dim3(DP_SYS_BLOCKS), dim3(DP_THREADS), 0, s1, d);
+            // up to 32 k entries, two per wave: enough blocks that none loops for long
+            hipLaunchKernelGGL(k_dp_sys<16>, dim3(4 * DP_SYS_BLOCKS), dim3(DP_THREADS), 0, s1, d);
             hipLaunchKernelGGL((k_dp_regs<16, 2>), dim3(DP_REG_BLOCKS), dim3(DP_THREADS), 0, s1, d);
         }
         if (s->max_aln_len > 16) {
             hipStream_t s2 = side(2);
-            hipLaunchKernelGGL(k_dp_sys<64>, dim3(DP_SYS_BLOCKS), dim3(DP_THREADS), 0, s2, d);
+            hipLaunchKernelGGL(k_dp_sys<64>, dim3(2 * DP_SYS_BLOCKS), dim3(DP_THREADS), 0, s2, d);
             hipLaunchKernelGGL((k_dp_regs<32, 3>), dim3(DP_REG_BLOCKS), dim3(DP_THREADS), 0, s2, d);
             if (s->max_aln_len > 32) {
                 if (dp_rows_fit_lds(s->max_aln_len))
