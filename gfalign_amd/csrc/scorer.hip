@@ -2466,17 +2466,18 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
         int want_groups = 8192;
         if (const char *env = getenv("GFAL_SCAN_GROUPS")) want_groups = std::max(1, atoi(env));
         int chunks = (want_groups + a.n_tiles - 1) / a.n_tiles;
-        // at least ~50 items per wave and workgroup: every workgroup re-stages its
-        // tile's images, which small shards cannot amortise otherwise
+        // at least ~100 items per wave and workgroup: every workgroup re-stages its
+        // tile's images, which small shards cannot amortise otherwise, and the
+        // item rejection works on 64 items of a wave at a time
         const int want_chunks = chunks;
-        const int max_chunks = std::max(1, s->n_items / (50 * SCAN_WAVES));
+        const int max_chunks = std::max(1, s->n_items / (100 * SCAN_WAVES));
         chunks = std::max(1, std::min(chunks, max_chunks));
         // small batches (what a search submits) end up with about one round of the
         // 2-per-CU resident workgroups, and tiles of long paths cost more than
         // tiles of short ones: trade staging for balance down to ~12 items per
         // wave until there are four rounds, and always fill the first round
         const int slots = 2 * s->n_cus;
-        if ((long long)a.n_tiles * chunks < 4LL * slots) {
+        if (a.n_tiles < slots && (long long)a.n_tiles * chunks < 4LL * slots) {
             const int balanced = std::min((4 * slots + a.n_tiles - 1) / a.n_tiles,
                                           std::max(1, s->n_items / (12 * SCAN_WAVES)));
             chunks = std::max(chunks, std::min(want_chunks, balanced));
