@@ -6,7 +6,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import oracle
-from gfalign_amd.scorer import Scorer
+from gfalign_amd.scorer import GFAL_STEP_OTHER, Scorer
 from helpers import csr, random_case, walk_case
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
@@ -33,6 +33,13 @@ for case in range(n_cases):
         n_nodes = V
     if rnd.random() < 0.2:
         alns[rnd.randrange(len(alns))] = []
+    if rnd.random() < 0.3:                      # path steps whose orientation equals nothing
+        for p in paths[:max(1, len(paths) // 4)]:
+            p[rnd.randrange(len(p))] |= GFAL_STEP_OTHER
+    universe = None
+    if rnd.random() < 0.3:                      # nodes the paths may visit: theirs plus a few
+        on_paths = {(s & ~GFAL_STEP_OTHER) >> 1 for p in paths for s in p}
+        universe = sorted(on_paths | {rnd.randrange(n_nodes) for _ in range(3)})
     aoff, ast = csr(alns)
     poff, pst = csr(paths)
     flt = rnd.random() < 0.7
@@ -40,7 +47,7 @@ for case in range(n_cases):
     n_shards = rnd.choice([1, 1, 2, 3, 5])
     acc = [np.zeros(len(paths), np.uint64) for _ in range(3)]
     for k in range(n_shards):
-        with Scorer(aoff, ast, n_nodes, shard=(k, n_shards)) as sc:
+        with Scorer(aoff, ast, n_nodes, universe=universe, shard=(k, n_shards)) as sc:
             for a, part in zip(acc, sc.evaluate_paths(poff, pst, flt)):
                 a += part
     exp = oracle.evaluate_paths(aoff, ast, poff, pst, flt)
