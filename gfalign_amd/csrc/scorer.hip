@@ -1195,53 +1195,39 @@ __device__ __forceinline__ bool dp_decide_regs(const uint16_t *__restrict__ aste
 __global__ __launch_bounds__(1024) void k_wl_offsets(const uint32_t *__restrict__ hist,
                                                       uint32_t *__restrict__ offsets,
                                                       uint32_t *__restrict__ cursor,
-                                                      uint32_t *__restrict__ class_lo,
+                                                      uint32_t *__restrict__ class_total,
                                                       int n_paths)
 {
-    // all classes side by side: one Hillis-Steele scan over the 1024 per-thread
-    // sums, five values wide
-    __shared__ uint32_t part[N_CLASSES][1024];
-    const int tid = threadIdx.x;
-    uint32_t sum[N_CLASSES];
-#pragma unroll
-    for (int c = 0; c < N_CLASSES; ++c) {
-        const uint32_t *h = hist + (size_t)c * n_paths;
-        uint32_t acc = 0;
-        for (int p = tid; p < n_paths; p += 1024) acc += h[p];
-        sum[c] = acc;
-        part[c][tid] = acc;
-    }
+    // one workgroup per length class: offsets relative to the start of the class
+    // and the class total; k_wl_scatter turns the totals into class_lo[]
+    __shared__ uint32_t part[1024];
+    const int tid = threadIdx.x, c = blockIdx.x;
+    const uint32_t *h = hist + (size_t)c * n_paths;
+    uint32_t sum = 0;
+    for (int p = tid; p < n_paths; p += 1024) sum += h[p];
+    part[tid] = sum;
     __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        uint32_t v[N_CLASSES];
-#pragma unroll
-        for (int c = 0; c < N_CLASSES; ++c) v[c] = tid >= o ? part[c][tid - o] : 0u;
+    for (int o = 1; o < 1024; o <<= 1) {      // Hillis-Steele inclusive scan
+        const uint32_t v = tid >= o ? part[tid - o] : 0u;
         __syncthreads();
-#pragma unroll
-        for (int c = 0; c < N_CLASSES; ++c) part[c][tid] += v[c];
+        part[tid] += v;
         __syncthreads();
     }
-    uint32_t class_base = 0;
-#pragma unroll
-    for (int c = 0; c < N_CLASSES; ++c) {
-        const uint32_t *h = hist + (size_t)c * n_paths;
-        uint32_t run = class_base + part[c][tid] - sum[c];
-        for (int p = tid; p < n_paths; p += 1024) {
-            offsets[(size_t)c * n_paths + p] = run;
-            cursor[(size_t)c * n_paths + p] = 0;
-            run += h[p];
-        }
-        if (tid == 0) class_lo[c] = class_base;
-        class_base += part[c][1023];
+    uint32_t run = part[tid] - sum;
+    for (int p = tid; p < n_paths; p += 1024) {
+        offsets[(size_t)c * n_paths + p] = run;
+        cursor[(size_t)c * n_paths + p] = 0;
+        run += h[p];
     }
-    if (tid == 0) class_lo[N_CLASSES] = class_base;
+    if (tid == 1023) class_total[c] = part[1023];
 }
 
 __global__ __launch_bounds__(256) void k_wl_scatter(
     Items items, const unsigned long long *__restrict__ worklist,
     const uint32_t *__restrict__ wl_count, uint32_t wl_capacity,
     const uint32_t *__restrict__ offsets, uint32_t *__restrict__ cursor,
-    uint32_t n_paths, unsigned long long *__restrict__ sorted)
+    uint32_t n_paths, unsigned long long *__restrict__ sorted,
+    const uint32_t *__restrict__ class_total, uint32_t *__restrict__ class_lo)
 {
     // overflow (status word set by k_scan): the histogram counted pairs that
     // were never stored, so offsets do not describe the list; the call fails
@@ -1250,6 +1236,14 @@ __global__ __launch_bounds__(256) void k_wl_scatter(
     const uint32_t total = *wl_count;
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t lane = threadIdx.x & (WAVE - 1);
+    // where the classes start: prefix of the class totals (k_wl_offsets); the
+    // first thread publishes it for the DP kernels
+    uint32_t class_base[N_CLASSES + 1];
+    class_base[0] = 0;
+#pragma unroll
+    for (int c = 0; c < N_CLASSES; ++c) class_base[c + 1] = class_base[c] + class_total[c];
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int c = 0; c <= N_CLASSES; ++c) class_lo[c] = class_base[c];
     // whole waves iterate together (the tail is padded with dead lanes)
     for (uint32_t w0 = blockIdx.x * blockDim.x + (threadIdx.x & ~(WAVE - 1)); w0 < total;
          w0 += stride) {
@@ -1258,8 +1252,11 @@ __global__ __launch_bounds__(256) void k_wl_scatter(
         const unsigned long long ent = live ? worklist[w] : 0ull;
         const uint32_t p = (uint32_t)(ent >> 32) & WL_PATH_MASK;
         const uint32_t it = (uint32_t)ent >> 6;
-        const uint32_t bin =
-            live ? (uint32_t)length_class((int)items.len[it]) * n_paths + p : 0xFFFFFFFFu;
+        const uint32_t cls = (uint32_t)length_class((int)items.len[it]);
+        const uint32_t bin = live ? cls * n_paths + p : 0xFFFFFFFFu;
+        uint32_t my_base = 0;
+#pragma unroll
+        for (int c = 0; c < N_CLASSES; ++c) my_base = cls == (uint32_t)c ? class_base[c] : my_base;
         // the scan appends runs of one (path, item): one atomic per run of equal
         // bins (all of a wave's runs in flight together), not one per entry --
         // on a search batch a whole wave often lands in a single bin
@@ -1276,7 +1273,7 @@ __global__ __launch_bounds__(256) void k_wl_scatter(
         if (live && (int)lane == head)
             base = atomicAdd(&cursor[bin], (uint32_t)__builtin_popcountll(run));
         base = (uint32_t)__shfl((int)base, head, WAVE);
-        const uint32_t at = live ? offsets[bin] + base + (uint32_t)(lane - head) : 0u;
+        const uint32_t at = live ? my_base + offsets[bin] + base + (uint32_t)(lane - head) : 0u;
         if (live) sorted[at] = ent;
     }
 }
@@ -2373,7 +2370,7 @@ static int ensure_call_buffers(gfal_scorer *s, int32_t n_paths, const ImageLayou
         int rc = dev_reserve(&s->d_images, &s->images_cap, want);
         if (rc) return rc;
     }
-    size_t bins = (size_t)3 * N_CLASSES * n_paths + 8;
+    size_t bins = (size_t)3 * N_CLASSES * n_paths + 16;   // + class_lo[6], class totals[5]
     if (bins > s->wl_bins_cap || (size_t)n_paths > s->order_cap) {
         if (s->have_last) HIP_TRY(hipStreamSynchronize(s->last_stream));
         int rc = dev_reserve(&s->d_wl_bins, &s->wl_bins_cap, bins);
@@ -2503,11 +2500,11 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
         s->last_lds = (int)lds;
         if (s->profiling) HIP_TRY(hipEventRecord(ev[2], st));
 
-        hipLaunchKernelGGL(k_wl_offsets, dim3(1), dim3(1024), 0, st, d_hist, d_offsets,
-                           d_cursor, d_class_lo, (int)n_paths);
+        hipLaunchKernelGGL(k_wl_offsets, dim3(N_CLASSES), dim3(1024), 0, st, d_hist, d_offsets,
+                           d_cursor, d_class_lo + 8, (int)n_paths);
         hipLaunchKernelGGL(k_wl_scatter, dim3(256), dim3(256), 0, st, a.items,
                            s->d_worklist, s->d_status + 1, s->wl_capacity, d_offsets,
-                           d_cursor, (uint32_t)n_paths, s->d_worklist_sorted);
+                           d_cursor, (uint32_t)n_paths, s->d_worklist_sorted, d_class_lo + 8, d_class_lo);
         DpArgs d;
         d.items = a.items;
         d.images = s->d_images;
