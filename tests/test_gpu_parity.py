@@ -314,6 +314,26 @@ def test_graph_replay_gives_the_same_counters(gpu, monkeypatch):
                 assert np.array_equal(g, e)
 
 
+def test_more_shards_than_items(gpu):
+    """Eight shards of three alignments: most shards own nothing (and one owns the
+    zero-step alignment); the counters still add up."""
+    alns = [[2, 4, 6], [], [7, 5], [2, 4]]
+    paths = [[2, 4, 6, 8], [6, 4, 2], [9], [2, 4]]
+    aoff, ast = csr(alns)
+    poff, pst = csr(paths)
+    exp = oracle.evaluate_paths(aoff, ast, poff, pst, True)
+    acc = [np.zeros(len(paths), np.uint64) for _ in range(3)]
+    owned = 0
+    for k in range(8):
+        with Scorer(aoff, ast, 8, shard=(k, 8)) as sc:
+            owned += sc.info()["n_aln"]
+            for a, part in zip(acc, sc.evaluate_paths(poff, pst, True)):
+                a += part
+    assert owned == len(alns)
+    for a, e in zip(acc, exp):
+        assert np.array_equal(a, e.astype(np.uint64))
+
+
 def test_worklist_overflow_splits_the_batch(gpu, monkeypatch):
     """More exact-DP pairs than the worklist holds: the blocking API halves the
     batch until every piece fits (a single path always does)."""
