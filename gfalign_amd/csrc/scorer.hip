@@ -663,9 +663,23 @@ __device__ __forceinline__ void scan_item(const ScanArgs &a, const TileView &tv,
     // the head lookup reads first[] (uint16 entries) through a dword
     const uint32_t node0_word = b0 >> 2, node0_shift = (b0 & 2u) << 3;
     const uint32_t o0 = (b0 & 1u) << 15;
-    // positions of the path's first step inside B, refreshed when a0 changes
-    uint32_t cached_a0 = 0xFFFFFFFFu, a0_fw = 0, a0_rc = 0;
-    lanemask a0_any = 0;    // lanes with a0_fw | a0_rc != 0
+    // Which lanes hold the tile's first step anywhere in B (either strand)?  Only
+    // those can have a start-overhang.  The candidate paths of a batch share their
+    // first step (the search's source), so this is computed once per item for the
+    // first step of tile path 0 and is loop-invariant: nothing per-lane is carried
+    // across the path loop (carried masks cost five register copies per path
+    // iteration).  A tile path with another first step takes the exact test always.
+    const uint32_t tile_a0 = (uint32_t)__builtin_amdgcn_readlane((int)tv.hdr_a0, 0);
+    lanemask a0_lanes;
+    {
+        bool has = ((b0 ^ tile_a0) & ~1u) == 0u;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            has |= (((pairs[k] & 0xFFFFu) ^ tile_a0) & ~1u) == 0u;
+            if (k + 1 < K || (M & 1)) has |= (((pairs[k] >> 16) ^ tile_a0) & ~1u) == 0u;
+        }
+        a0_lanes = WAVE_MASK(has);
+    }
 
     for (int p = 0; p < tv.tile_paths; ++p) {
         const lanemask in_m = WAVE_MASK(((pass >> p) & 1u) != 0u);
@@ -706,11 +720,12 @@ __device__ __forceinline__ void scan_item(const ScanArgs &a, const TileView &tv,
             // proper suffix of B (or of rc(B)) equals a prefix of the path
             // ("start-overhang").  Exact test; survivors go to the DP kernels.
             const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)tv.hdr_a0, p);
-            if (a0 != cached_a0) {
-                cached_a0 = a0;
+            const lanemask maybe_m = a0 == tile_a0 ? (open_m & a0_lanes) : open_m;
+            lanemask cand_m = 0;
+            if (maybe_m != 0) {
                 // bit t-1 of a0_fw: b[t] == a0 (t >= 1); bit t of a0_rc: b[t]^1 == a0 (t <= M-2)
-                a0_fw = 0;
-                a0_rc = (M >= 2 && (b0 ^ 1u) == a0) ? 1u : 0u;
+                uint32_t a0_fw = 0;
+                uint32_t a0_rc = (M >= 2 && (b0 ^ 1u) == a0) ? 1u : 0u;
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
                     const uint32_t lo = pairs[k] & 0xFFFFu, hi = pairs[k] >> 16;
@@ -722,11 +737,6 @@ __device__ __forceinline__ void scan_item(const ScanArgs &a, const TileView &tv,
                         a0_rc |= (t_hi <= M - 2 && (hi ^ 1u) == a0) ? (1u << t_hi) : 0u;
                     }
                 }
-                a0_any = WAVE_MASK((a0_fw | a0_rc) != 0u);
-            }
-            const lanemask maybe_m = open_m & a0_any;
-            lanemask cand_m = 0;
-            if (maybe_m != 0) {
                 const bool open = (open_m >> lane) & 1ull;
                 bool cand_fw = false, cand_rc = false;
                 for (int t = 1; t < M; ++t) {      // B[t..M) == path[0..M-t) ?
