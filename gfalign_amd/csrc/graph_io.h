@@ -148,50 +148,6 @@ inline void gaf_path_nodes(const std::string &path,
     }
 }
 
-inline bool read_gaf(const std::string &file, std::vector<GafRecord> &out, std::string &err)
-{
-    std::ifstream in(file);
-    if (!in) {
-        err = "cannot open " + file;
-        return false;
-    }
-    std::string line;
-    while (std::getline(in, line)) {
-        if (!line.empty() && line.back() == '\r') line.pop_back();
-        auto cols = split(line, '\t');
-        if (cols.size() < 12) {
-            err = "GAF record with fewer than 12 columns: " + line;
-            return false;
-        }
-        GafRecord r;
-        try {
-            r.qname = cols[0];
-            r.qlen = (unsigned)std::stoi(cols[1]);
-            r.qstart = (unsigned)std::stoi(cols[2]);
-            r.qend = (unsigned)std::stoi(cols[3]);
-            r.strand = cols[4].empty() ? '+' : cols[4][0];
-            r.path = cols[5];
-            r.plen = (unsigned)std::stoi(cols[6]);
-            r.pstart = (unsigned)std::stoi(cols[7]);
-            r.pend = (unsigned)std::stoi(cols[8]);
-            r.matches = (unsigned)std::stoi(cols[9]);
-            r.blocklen = (unsigned)std::stoi(cols[10]);
-            r.mapq = (unsigned)std::stoi(cols[11]);
-        } catch (const std::exception &) {
-            err = "malformed GAF record: " + line;
-            return false;
-        }
-        for (size_t c = 12; c < cols.size(); ++c) {
-            // reference keeps label[2], type, content (src/alignments.cpp:221-229)
-            auto t = split(cols[c], ':');
-            if (t.size() >= 3 && t[0].size() >= 2 && !t[1].empty())
-                r.tags.push_back(t[0].substr(0, 2) + ":" + t[1].substr(0, 1) + ":" + t[2]);
-        }
-        out.push_back(std::move(r));
-    }
-    return true;
-}
-
 // ---------------------------------------------------------------------------
 // `search` needs one thing from the GAF: the path column of every record as
 // packed steps (reference src/eval.cpp:123 getPaths -> src/alignments.cpp:75-94).
@@ -360,6 +316,115 @@ inline bool read_gaf_paths(const std::string &file, const Graph &g, std::vector<
         for (int32_t len : pc.lens) off.push_back(off.back() + len);
         steps.insert(steps.end(), pc.steps.begin(), pc.steps.end());
     }
+    return true;
+}
+
+// One line of a GAF -> record (reference src/alignments.cpp:143-235): 12 columns
+// at least, the numeric ones through std::stoi, tags as label[2]:type:content.
+inline bool parse_gaf_record(const std::string &line, GafRecord &r, std::string &err)
+{
+    auto cols = split(line, '\t');
+    if (cols.size() < 12) {
+        err = "GAF record with fewer than 12 columns: " + line;
+        return false;
+    }
+    try {
+        r.qname = cols[0];
+        r.qlen = (unsigned)std::stoi(cols[1]);
+        r.qstart = (unsigned)std::stoi(cols[2]);
+        r.qend = (unsigned)std::stoi(cols[3]);
+        r.strand = cols[4].empty() ? '+' : cols[4][0];
+        r.path = cols[5];
+        r.plen = (unsigned)std::stoi(cols[6]);
+        r.pstart = (unsigned)std::stoi(cols[7]);
+        r.pend = (unsigned)std::stoi(cols[8]);
+        r.matches = (unsigned)std::stoi(cols[9]);
+        r.blocklen = (unsigned)std::stoi(cols[10]);
+        r.mapq = (unsigned)std::stoi(cols[11]);
+    } catch (const std::exception &) {
+        err = "malformed GAF record: " + line;
+        return false;
+    }
+    for (size_t c = 12; c < cols.size(); ++c) {
+        // reference keeps label[2], type, content (src/alignments.cpp:221-229)
+        auto t = split(cols[c], ':');
+        if (t.size() >= 3 && t[0].size() >= 2 && !t[1].empty())
+            r.tags.push_back(t[0].substr(0, 2) + ":" + t[1].substr(0, 1) + ":" + t[2]);
+    }
+    return true;
+}
+
+// All records of a GAF, in file order (filter, evalGFA, evalPath).  The file is
+// mapped and cut into line-aligned pieces that are parsed on several threads
+// (the reference loads alignments through its thread pool too,
+// src/alignments.cpp:182); the first bad line in file order is the error.
+inline bool read_gaf(const std::string &file, std::vector<GafRecord> &out, std::string &err,
+                     unsigned n_threads = 0)
+{
+    int fd = open(file.c_str(), O_RDONLY);
+    if (fd < 0) {
+        err = "cannot open " + file;
+        return false;
+    }
+    struct stat st;
+    if (fstat(fd, &st) != 0) {
+        close(fd);
+        err = "cannot stat " + file;
+        return false;
+    }
+    const size_t size = (size_t)st.st_size;
+    if (size == 0) {
+        close(fd);
+        return true;
+    }
+    void *map = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (map == MAP_FAILED) {
+        err = "cannot map " + file;
+        return false;
+    }
+    const char *data = static_cast<const char *>(map);
+    if (n_threads == 0) n_threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    n_threads = (unsigned)std::min<size_t>(n_threads, size / (1 << 20) + 1);
+    std::vector<size_t> cut(n_threads + 1, size);
+    cut[0] = 0;
+    for (unsigned t = 1; t < n_threads; ++t) {
+        size_t at = std::max(cut[t - 1], size / n_threads * t);
+        const void *nl = at < size ? memchr(data + at, '\n', size - at) : nullptr;
+        cut[t] = nl ? (size_t)(static_cast<const char *>(nl) - data) + 1 : size;
+    }
+    std::vector<std::vector<GafRecord>> pieces(n_threads);
+    std::vector<std::string> errs(n_threads);
+    auto parse = [&](unsigned t) {
+        const char *p = data + cut[t], *const end = data + cut[t + 1];
+        std::string line;
+        while (p < end) {
+            const char *nl = static_cast<const char *>(memchr(p, '\n', (size_t)(end - p)));
+            const char *e = nl ? nl : end;
+            line.assign(p, e);
+            if (!line.empty() && line.back() == '\r') line.pop_back();
+            GafRecord r;
+            if (!parse_gaf_record(line, r, errs[t])) return;
+            pieces[t].push_back(std::move(r));
+            p = nl ? nl + 1 : end;
+        }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < n_threads; ++t) pool.emplace_back(parse, t);
+    parse(0);
+    for (auto &th : pool) th.join();
+    munmap(map, size);
+    size_t total = 0;
+    for (unsigned t = 0; t < n_threads; ++t) {
+        if (!errs[t].empty()) {
+            err = errs[t];
+            return false;
+        }
+        total += pieces[t].size();
+    }
+    out.reserve(out.size() + total);
+    for (auto &pc : pieces)
+        for (auto &r : pc) out.push_back(std::move(r));
     return true;
 }
 
