@@ -151,6 +151,9 @@ struct Items {
     const uint32_t *common;
     // {base, pbase, common, len} of every item in one 16-byte load (k_scan)
     const uint4 *hdr;
+    // gfal_scorer_create_dedup only (else NULL): how many identical alignments of
+    // the caller a lane stands for, [item * 64 + lane]
+    const uint32_t *weight;
 };
 constexpr uint32_t NO_COMMON_NODE = 0xFFFFFFFFu;
 
@@ -495,6 +498,17 @@ using lanemask = unsigned long long;
 
 // Per-(wave, tile path) counters: lane p of `packed` holds good | bad << 16 for
 // tile path p; flushed into the 32-bit lanes before 16 bits can overflow.
+// Sum of w over the lanes of `mask` (all lanes get the result).  Dedup scorers
+// only: a lane then stands for w identical alignments.
+__device__ __forceinline__ uint32_t wave_weight(lanemask mask, uint32_t w, int lane)
+{
+    if (mask == 0) return 0u;
+    uint32_t v = ((mask >> lane) & 1ull) ? w : 0u;
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) v += (uint32_t)__shfl_xor((int)v, o, WAVE);
+    return v;
+}
+
 struct WaveCounts {
     uint32_t packed = 0, good = 0, bad = 0;
     int items = 0;
@@ -502,6 +516,19 @@ struct WaveCounts {
     {
         const uint32_t inc = (uint32_t)__popcll(good_m) | ((uint32_t)__popcll(bad_m) << 16);
         if (lane == p) packed += inc;
+    }
+    // dedup scorers: weights instead of lane counts, straight into the 32-bit sums.
+    // all_m / w_all: the item's lanes and their total weight -- the usual masks
+    // (all lanes found, or none) need no reduction
+    __device__ __forceinline__ void add_weighted(int p, int lane, lanemask good_m, lanemask bad_m,
+                                                 uint32_t w, lanemask all_m, uint32_t w_all)
+    {
+        const uint32_t gw = good_m == all_m ? w_all : wave_weight(good_m, w, lane);
+        const uint32_t bw = bad_m == all_m ? w_all : wave_weight(bad_m, w, lane);
+        if (lane == p) {
+            good += gw;
+            bad += bw;
+        }
     }
     __device__ __forceinline__ void flush()
     {
@@ -631,12 +658,21 @@ __device__ __forceinline__ lanemask subpath_search_long(const uint16_t *__restri
 // One item against the tile.  K = M / 2 pair dwords per lane live in
 // registers; M (wave-uniform) is 2K or 2K + 1, a compile-time constant MC for
 // short alignments (MC = 0: run-time).
-template <int K, int MC>
+// W: dedup scorer (lane weights `w`); a separate instantiation, so that the
+// plain kernel carries nothing for it.
+template <int K, int MC, bool W>
 __device__ __forceinline__ void scan_item(const ScanArgs &a, const TileView &tv,
                                           const uint16_t *__restrict__ bp,
                                           const uint32_t *__restrict__ pp, int M_rt, int lane,
-                                          uint32_t slot, WaveCounts &wc)
+                                          uint32_t slot, WaveCounts &wc, uint32_t w)
 {
+    // dedup: the item's lanes and their total weight, once per item
+    const lanemask all_m = W ? WAVE_MASK(bp[0] != STEP_INVALID) : 0ull;
+    const uint32_t w_all = W ? wave_weight(all_m, w, lane) : 0u;
+    auto count = [&](int p, lanemask good_m, lanemask bad_m) {
+        if (W) wc.add_weighted(p, lane, good_m, bad_m, w, all_m, w_all);
+        else wc.add(p, lane, good_m, bad_m);
+    };
     const int M = MC ? MC : M_rt;
     uint32_t b0 = bp[0];
     uint32_t pairs[K ? K : 1];
@@ -686,7 +722,7 @@ __device__ __forceinline__ void scan_item(const ScanArgs &a, const TileView &tv,
         if (in_m == 0) continue;
         const int n = __builtin_amdgcn_readlane(tv.hdr_n, p);
         if (M > n) {                      // src/alignments.cpp:500 row-0 bound:
-            wc.add(p, lane, in_m, 0);     // longer than the path -> good
+            count(p, in_m, 0);            // longer than the path -> good
             continue;
         }
         const uint16_t *img = tv.lds + p * a.L.total;
@@ -701,7 +737,7 @@ __device__ __forceinline__ void scan_item(const ScanArgs &a, const TileView &tv,
         cv.dbg = a.status + 2;
 #endif
 #if defined(GFAL_ABLATE) && GFAL_ABLATE == 2
-        wc.add(p, lane, in_m, 0);
+        count(p, in_m, 0);
         continue;
 #endif
         // every lane searches (a lane that is not `in` misses a node of the
@@ -754,16 +790,24 @@ __device__ __forceinline__ void scan_item(const ScanArgs &a, const TileView &tv,
             }
             bad_m = open_m & ~cand_m;
         }
-        wc.add(p, lane, found_m, bad_m);
+        count(p, found_m, bad_m);
     }
     wc.item_done();
 }
 
 // Same decision for alignments too long for registers.
+template <bool W>
 __device__ __forceinline__ void scan_item_long(const ScanArgs &a, const TileView &tv,
                                                const uint16_t *__restrict__ bp, int M,
-                                               int lane, uint32_t slot, WaveCounts &wc)
+                                               int lane, uint32_t slot, WaveCounts &wc, uint32_t w)
 {
+    // dedup: the item's lanes and their total weight, once per item
+    const lanemask all_m = W ? WAVE_MASK(bp[0] != STEP_INVALID) : 0ull;
+    const uint32_t w_all = W ? wave_weight(all_m, w, lane) : 0u;
+    auto count = [&](int p, lanemask good_m, lanemask bad_m) {
+        if (W) wc.add_weighted(p, lane, good_m, bad_m, w, all_m, w_all);
+        else wc.add(p, lane, good_m, bad_m);
+    };
     const uint32_t first_step = bp[0];
     const bool valid = first_step != STEP_INVALID;
     const uint32_t b0 = valid ? first_step : 0u;
@@ -779,7 +823,7 @@ __device__ __forceinline__ void scan_item_long(const ScanArgs &a, const TileView
         if (in_m == 0) continue;
         const int n = __builtin_amdgcn_readlane(tv.hdr_n, p);
         if (M > n) {
-            wc.add(p, lane, in_m, 0);
+            count(p, in_m, 0);
             continue;
         }
         const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)tv.hdr_a0, p);
@@ -810,11 +854,12 @@ __device__ __forceinline__ void scan_item_long(const ScanArgs &a, const TileView
             bad_m = open_m & ~WAVE_MASK(cand_fw || cand_rc);
             push_pairs(a, cand_fw, cand_rc, lane, (uint32_t)(tv.path0 + p), slot, M);
         }
-        wc.add(p, lane, found_m, bad_m);
+        count(p, found_m, bad_m);
     }
     wc.item_done();
 }
 
+template <bool W>
 __global__ __launch_bounds__(SCAN_THREADS, 6) void k_scan(ScanArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
@@ -900,14 +945,15 @@ __global__ __launch_bounds__(SCAN_THREADS, 6) void k_scan(ScanArgs a)
         const uint16_t *bp = a.items.steps + (size_t)base_v * WAVE + lane;
         const uint32_t slot = (uint32_t)it * WAVE + lane;
         const uint32_t *pp = a.items.pairs + (size_t)pbase_v * WAVE + lane;
+        const uint32_t w = W ? a.items.weight[slot] : 1u;
         if (M > 2 * MAX_REG_K + 1) {
-            scan_item_long(a, tv, bp, M, lane, slot, wc);
+            scan_item_long<W>(a, tv, bp, M, lane, slot, wc, w);
             continue;
         }
         switch (M) {
 #define GFAL_CASE(MM)                                                          \
     case MM:                                                                   \
-        scan_item<MM / 2, MM>(a, tv, bp, pp, M, lane, slot, wc);               \
+        scan_item<MM / 2, MM, W>(a, tv, bp, pp, M, lane, slot, wc, w);         \
         break;
             GFAL_CASE(1) GFAL_CASE(2) GFAL_CASE(3) GFAL_CASE(4)
             GFAL_CASE(5) GFAL_CASE(6) GFAL_CASE(7) GFAL_CASE(8)
@@ -917,9 +963,9 @@ __global__ __launch_bounds__(SCAN_THREADS, 6) void k_scan(ScanArgs a)
 #define GFAL_CASE(KK)                                                          \
     case 2 * KK:                                                               \
     case 2 * KK + 1:                                                           \
-        scan_item<KK, 0>(a, tv, bp, pp, M, lane, slot, wc);                    \
+        scan_item<KK, 0, W>(a, tv, bp, pp, M, lane, slot, wc, w);              \
         break;
-            case 17: scan_item<8, 0>(a, tv, bp, pp, M, lane, slot, wc); break;
+            case 17: scan_item<8, 0, W>(a, tv, bp, pp, M, lane, slot, wc, w); break;
             GFAL_CASE(9) GFAL_CASE(10) GFAL_CASE(11) GFAL_CASE(12)
             GFAL_CASE(13) GFAL_CASE(14) GFAL_CASE(15) GFAL_CASE(16)
 #undef GFAL_CASE
@@ -1315,6 +1361,7 @@ struct DpEntry {
     const uint16_t *astep, *bp;
     int n, m;
     bool has_fw, has_rc;
+    uint32_t w;     // identical alignments this entry stands for (1 unless a dedup scorer)
 };
 
 __device__ __forceinline__ DpEntry load_entry(const DpArgs &a, uint32_t w, bool live)
@@ -1331,6 +1378,7 @@ __device__ __forceinline__ DpEntry load_entry(const DpArgs &a, uint32_t w, bool 
     e.bp = a.items.steps + (size_t)(live ? a.items.base[it] : 0u) * WAVE + ln;
     e.has_fw = (ent & WL_FW) != 0;
     e.has_rc = (ent & WL_RC) != 0;
+    e.w = (live && a.items.weight) ? a.items.weight[slot] : 1u;
     return e;
 }
 
@@ -1356,21 +1404,28 @@ __device__ __forceinline__ bool wavefront_class(const DpArgs &a, uint32_t total,
 // lane -- all resident waves work on the same few paths at a time, and per-lane
 // atomics on those few words were 75 % of the DP phase.
 __device__ __forceinline__ void add_results_by_path(const DpArgs &a, uint32_t p, bool live,
-                                                    bool good, int lane)
+                                                    bool good, int lane, uint32_t w = 1u)
 {
     const uint32_t prev_p = (uint32_t)__shfl_up((int)p, 1, WAVE);
     const lanemask live_mask = WAVE_MASK(live), good_mask = WAVE_MASK(good && live);
     // a run starts at a live lane whose left neighbour is dead or on another path
     const lanemask starts =
         WAVE_MASK(live && (lane == 0 || p != prev_p || !((live_mask >> (lane - 1)) & 1ull)));
+    const bool weighted = a.items.weight != nullptr;      // dedup scorer: sums of weights
     lanemask left = starts;
     while (left) {
         const int leader = __builtin_ctzll(left);
         left &= left - 1;
         const lanemask upto = left ? ((1ull << __builtin_ctzll(left)) - 1ull) : ~0ull;
         const lanemask mine = upto & ~((1ull << leader) - 1ull) & live_mask;
-        const uint32_t n_good = (uint32_t)__builtin_popcountll(mine & good_mask);
-        const uint32_t n_bad = (uint32_t)__builtin_popcountll(mine) - n_good;
+        uint32_t n_good, n_bad;
+        if (weighted) {
+            n_good = wave_weight(mine & good_mask, w, lane);
+            n_bad = wave_weight(mine & ~good_mask, w, lane);
+        } else {
+            n_good = (uint32_t)__builtin_popcountll(mine & good_mask);
+            n_bad = (uint32_t)__builtin_popcountll(mine) - n_good;
+        }
         if (lane == leader) {
             if (n_good) atomicAdd(&a.counts[a.n_paths + p], n_good);
             if (n_bad) atomicAdd(&a.counts[p], n_bad);
@@ -1444,7 +1499,7 @@ __global__ __launch_bounds__(DP_THREADS) void k_dp_regs(DpArgs a)
 #if defined(GFAL_ABLATE) && GFAL_ABLATE == 3
         good = false;
 #endif
-        add_results_by_path(a, e.p, live, good, lane);
+        add_results_by_path(a, e.p, live, good, lane, e.w);
     }
 }
 
@@ -1663,7 +1718,7 @@ __global__ __launch_bounds__(DP_THREADS) void k_dp_sys(DpArgs a)
         const lanemask gm = WAVE_MASK(good);
         const lanemask mine = (gm >> (lane / SPAN * SPAN)) & (SPAN == 64 ? ~0ull : ((1ull << SPAN) - 1ull));
         // one result per entry, carried by the first lane of its span
-        add_results_by_path(a, e.p, live && lane % SPAN == 0, mine != 0, lane);
+        add_results_by_path(a, e.p, live && lane % SPAN == 0, mine != 0, lane, e.w);
     }
 }
 
@@ -1692,7 +1747,7 @@ __global__ __launch_bounds__(DP_THREADS) void k_dp_long(DpArgs a)
         B.flip = 1u;
         const int rc = traceback_score(A, B, row, stride);
         const bool good = fw == 0 || rc == 0;
-        add_results_by_path(a, e.p, mine, good, (int)threadIdx.x);
+        add_results_by_path(a, e.p, mine, good, (int)threadIdx.x, e.w);
     }
 }
 
@@ -1753,6 +1808,9 @@ struct gfal_scorer {
     uint32_t *d_item_pbase = nullptr;
     uint32_t *d_item_common = nullptr;   // Items::common
     uint4 *d_item_hdr = nullptr;         // Items::hdr
+    uint32_t *d_item_weight = nullptr;   // Items::weight (dedup scorers)
+    int64_t n_lanes = 0;                 // alignments resident on the device (distinct ones if dedup)
+    std::vector<int32_t> rep_of;         // dedup: caller's alignment -> the identical one that is resident
     int32_t *d_slot_orig = nullptr;    // [n_items*64] original index or -1
     uint32_t *d_status = nullptr;      // [4]: status word, worklist count, 2 debug words
     unsigned long long *d_worklist = nullptr;   // as pushed by k_scan
@@ -1843,7 +1901,8 @@ void free_scorer(gfal_scorer *s)
 {
     if (!s) return;
     (void)hipSetDevice(s->device);
-    void *bufs[] = {s->d_item_pairs, s->d_item_pbase, s->d_item_common, s->d_item_hdr, s->d_len_bins, s->d_order,
+    void *bufs[] = {s->d_item_pairs, s->d_item_pbase, s->d_item_common, s->d_item_hdr, s->d_item_weight,
+                    s->d_len_bins, s->d_order,
                     s->d_counts_slot,
                     s->d_node_local, s->d_node_hist, s->d_item_steps, s->d_item_base,
                     s->d_item_len,   s->d_slot_orig, s->d_status,     s->d_worklist,
@@ -1928,10 +1987,31 @@ int gfal_scorer_create_ex(const int32_t *aln_off, const int32_t *aln_steps,
                                       n_universe, 0, 1, out);
 }
 
+static int create_impl(const int32_t *aln_off, const int32_t *aln_steps, int64_t n_aln,
+                       int32_t n_nodes, int device, const int32_t *universe, int32_t n_universe,
+                       int32_t shard_index, int32_t n_shards, bool dedup, gfal_scorer **out);
+
 int gfal_scorer_create_sharded(const int32_t *aln_off, const int32_t *aln_steps,
                                int64_t n_aln, int32_t n_nodes, int device,
                                const int32_t *universe, int32_t n_universe,
                                int32_t shard_index, int32_t n_shards, gfal_scorer **out)
+{
+    return create_impl(aln_off, aln_steps, n_aln, n_nodes, device, universe, n_universe,
+                       shard_index, n_shards, false, out);
+}
+
+int gfal_scorer_create_dedup(const int32_t *aln_off, const int32_t *aln_steps,
+                             int64_t n_aln, int32_t n_nodes, int device,
+                             const int32_t *universe, int32_t n_universe,
+                             int32_t shard_index, int32_t n_shards, gfal_scorer **out)
+{
+    return create_impl(aln_off, aln_steps, n_aln, n_nodes, device, universe, n_universe,
+                       shard_index, n_shards, true, out);
+}
+
+static int create_impl(const int32_t *aln_off, const int32_t *aln_steps, int64_t n_aln,
+                       int32_t n_nodes, int device, const int32_t *universe, int32_t n_universe,
+                       int32_t shard_index, int32_t n_shards, bool dedup, gfal_scorer **out)
 {
     if (!out) return GFAL_E_ARG;
     *out = nullptr;
@@ -2173,17 +2253,47 @@ int gfal_scorer_create_sharded(const int32_t *aln_off, const int32_t *aln_steps,
         for (auto &t : pool) t.join();
     }
     mark("bucket + sort");
+    // dedup: runs of identical alignments (neighbours in the content order) become
+    // one lane with a weight; rep_of[] remembers who stands for whom
+    std::vector<std::vector<uint32_t>> wt_len;
+    std::vector<int32_t> rep_of;
+    if (dedup) {
+        wt_len.resize((size_t)max_len + 1);
+        rep_of.resize((size_t)n_aln);
+        for (int64_t k = 0; k < n_aln; ++k) rep_of[(size_t)k] = (int32_t)k;
+        const uint16_t *ls = local_steps.data();
+        for (int m = 1; m <= max_len; ++m) {
+            std::vector<int32_t> &idx = by_len[(size_t)m];
+            std::vector<int32_t> reps;
+            std::vector<uint32_t> &wts = wt_len[(size_t)m];
+            for (size_t i = 0; i < idx.size(); ++i) {
+                const bool same = !reps.empty() &&
+                                  memcmp(ls + aln_off[reps.back()], ls + aln_off[idx[i]],
+                                         (size_t)m * sizeof(uint16_t)) == 0;
+                if (same) {
+                    ++wts.back();
+                    rep_of[(size_t)idx[i]] = reps.back();
+                } else {
+                    reps.push_back(idx[i]);
+                    wts.push_back(1u);
+                }
+            }
+            idx.swap(reps);
+        }
+        mark("dedup");
+    }
     // item directory first (sequential, cheap), then the lanes are filled in
     // parallel: every item writes its own ranges
     struct ItemSrc {
         const int32_t *idx;   // the item's alignments (original indices)
+        const uint32_t *wt;   // their weights (dedup) or NULL
         int cnt, m;
     };
     std::vector<ItemSrc> src;
     std::vector<uint32_t> item_base, item_pbase;
     std::vector<uint16_t> item_len;
     uint64_t global_item = 0, n_u16 = 0, n_pairs = 0;
-    int64_t own_aln = n_empty, own_steps = 0;
+    int64_t own_aln = n_empty, own_steps = 0, n_lanes = 0;
     for (int m = 1; m <= max_len; ++m) {
         const std::vector<int32_t> &idx = by_len[(size_t)m];
         for (size_t at = 0; at < idx.size(); at += WAVE) {
@@ -2192,14 +2302,19 @@ int gfal_scorer_create_sharded(const int32_t *aln_off, const int32_t *aln_steps,
             // are a subset of the unsharded ones (same lanes side by side), so the
             // scan kernel does on 1/n of the items exactly 1/n of the work
             if ((int32_t)(global_item++ % (uint64_t)n_shards) != shard_index) continue;
-            src.push_back(ItemSrc{idx.data() + at, (int)cnt, m});
+            const uint32_t *wt = dedup ? wt_len[(size_t)m].data() + at : nullptr;
+            src.push_back(ItemSrc{idx.data() + at, wt, (int)cnt, m});
             item_base.push_back((uint32_t)(n_u16 / WAVE));
             item_pbase.push_back((uint32_t)(n_pairs / WAVE));
             item_len.push_back((uint16_t)m);
             n_u16 += (uint64_t)m * WAVE;
             n_pairs += (uint64_t)(m / 2) * WAVE;
-            own_aln += (int64_t)cnt;
-            own_steps += (int64_t)cnt * m;
+            for (size_t l = 0; l < cnt; ++l) {
+                const int64_t w = wt ? wt[l] : 1;
+                own_aln += w;
+                own_steps += w * m;
+            }
+            n_lanes += (int64_t)cnt;
         }
     }
     if (n_u16 / WAVE >= ((uint64_t)1 << 32) || src.size() >= ((size_t)1 << 25)) {
@@ -2210,6 +2325,7 @@ int gfal_scorer_create_sharded(const int32_t *aln_off, const int32_t *aln_steps,
     std::vector<uint32_t> item_pairs((size_t)n_pairs, 0xFFFFFFFFu);
     std::vector<int32_t> slot_orig(src.size() * WAVE, -1);
     std::vector<uint32_t> item_common(src.size(), NO_COMMON_NODE);
+    std::vector<uint32_t> item_weight(dedup ? src.size() * WAVE : 0, 0u);
     {
         unsigned n_threads = std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency()));
         if (const char *env = getenv("GFAL_CREATE_THREADS")) n_threads = (unsigned)std::max(1, atoi(env));
@@ -2226,9 +2342,11 @@ int gfal_scorer_create_sharded(const int32_t *aln_off, const int32_t *aln_steps,
                 uint32_t *pairs = item_pairs.data() + (size_t)item_pbase[it] * WAVE;
                 for (int l = 0; l < is.cnt; ++l) {
                     const uint16_t *px = ls + aln_off[is.idx[l]];
+                    const uint32_t w = is.wt ? is.wt[l] : 1u;
+                    if (is.wt) item_weight[it * WAVE + (size_t)l] = w;
                     for (int t = 0; t < m; ++t) {
                         steps[(size_t)t * WAVE + l] = px[t];
-                        ++h[px[t] >> 1];
+                        h[px[t] >> 1] += w;
                     }
                     for (int k = 0; k < K; ++k)
                         pairs[(size_t)k * WAVE + l] =
@@ -2280,6 +2398,12 @@ int gfal_scorer_create_sharded(const int32_t *aln_off, const int32_t *aln_steps,
     if (shard_index == 0)
         for (int64_t k = 0; k < n_aln; ++k)
             if (aln_off[k + 1] == aln_off[k]) s->owned[(size_t)k] = 1;
+    if (dedup) {      // the copies go where their representative goes
+        for (int64_t k = 0; k < n_aln; ++k)
+            if (s->owned[(size_t)rep_of[(size_t)k]]) s->owned[(size_t)k] = 1;
+        s->rep_of.swap(rep_of);
+    }
+    s->n_lanes = n_lanes;
     s->n_nodes = n_nodes;
     s->n_local = n_local;
     s->max_aln_len = max_len;
@@ -2310,7 +2434,10 @@ int gfal_scorer_create_sharded(const int32_t *aln_off, const int32_t *aln_steps,
         CREATE_TRY(hipEventCreateWithFlags(&s->dp_join[i], hipEventDisableTiming));
     }
     // both kernels may ask for more than the default 64 KiB of dynamic LDS
-    CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan),
+    CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan<false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   LDS_BUDGET));
+    CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan<true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize,
                                    LDS_BUDGET));
     CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_prep),
@@ -2323,6 +2450,7 @@ int gfal_scorer_create_sharded(const int32_t *aln_off, const int32_t *aln_steps,
     if ((rc = dev_upload(&s->d_item_pairs, item_pairs))) return fail(rc);
     if ((rc = dev_upload(&s->d_item_pbase, item_pbase))) return fail(rc);
     if ((rc = dev_upload(&s->d_item_common, item_common))) return fail(rc);
+    if (dedup && (rc = dev_upload(&s->d_item_weight, item_weight))) return fail(rc);
     {
         std::vector<uint4> item_hdr(src.size());
         for (size_t it = 0; it < src.size(); ++it)
@@ -2458,7 +2586,7 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
     if (s->n_items > 0) {
         ScanArgs a;
         a.items = Items{s->d_item_steps, s->d_item_base, s->d_item_len, s->d_item_pairs,
-                        s->d_item_pbase, s->n_items, s->d_item_common, s->d_item_hdr};
+                        s->d_item_pbase, s->n_items, s->d_item_common, s->d_item_hdr, s->d_item_weight};
         a.images = s->d_images;
         a.L = L;
         a.n_paths = n_paths;
@@ -2503,7 +2631,10 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
         const size_t lds = std::max((size_t)tile * img_bytes + mask_bytes,
                                     (size_t)2 * MAX_TILE * sizeof(uint32_t));
         const unsigned grid = (unsigned)a.n_tiles * (unsigned)a.n_chunks;
-        hipLaunchKernelGGL(k_scan, dim3(grid), dim3(SCAN_THREADS), lds, st, a);
+        if (s->d_item_weight)
+            hipLaunchKernelGGL(k_scan<true>, dim3(grid), dim3(SCAN_THREADS), lds, st, a);
+        else
+            hipLaunchKernelGGL(k_scan<false>, dim3(grid), dim3(SCAN_THREADS), lds, st, a);
         HIP_TRY(hipGetLastError());
         s->last_tile = tile;
         s->last_grid = (int)grid;
@@ -2784,7 +2915,7 @@ int gfal_scorer_pair_scores(gfal_scorer *s, const int32_t *path_steps, int32_t n
                        (long long)n_in, 0);
     if (s->n_items > 0) {
         Items items{s->d_item_steps, s->d_item_base, s->d_item_len, s->d_item_pairs,
-                    s->d_item_pbase, s->n_items, s->d_item_common, s->d_item_hdr};
+                    s->d_item_pbase, s->n_items, s->d_item_common, s->d_item_hdr, s->d_item_weight};
         if (dp_rows_fit_lds(s->max_aln_len))
             hipLaunchKernelGGL(k_pairs<true>, dim3(DP_BLOCKS), dim3(DP_THREADS),
                                dp_lds_bytes(s->max_aln_len), s->stream, items,
@@ -2811,10 +2942,12 @@ int gfal_scorer_pair_scores(gfal_scorer *s, const int32_t *path_steps, int32_t n
     }
     // only this shard's alignments are written: the shards of one alignment set
     // fill one pair of arrays between them
+    const bool dedup = !s->rep_of.empty();       // a copy takes its representative's scores
     for (size_t k = 0; k < n_in; ++k)
         if (s->owned[k]) {
-            fw[k] = h_fw[k];
-            rc_out[k] = h_rc[k];
+            const size_t from = dedup ? (size_t)s->rep_of[k] : k;
+            fw[k] = h_fw[from];
+            rc_out[k] = h_rc[from];
         }
     s->last_stream = s->stream;
     s->have_last = true;
@@ -2833,6 +2966,7 @@ int gfal_scorer_get_info(gfal_scorer *s, gfal_info *out)
     out->tile_paths = s->last_tile;
     out->n_workgroups = s->last_grid;
     out->lds_bytes = s->last_lds;
+    out->n_lanes = s->n_lanes;
     if (s->have_last) {
         HIP_TRY(hipSetDevice(s->device));
         uint32_t host[4] = {0, 0, 0, 0};

@@ -192,8 +192,11 @@ public:
         shards_.assign((size_t)n_devices, nullptr);
         std::vector<int> rcs((size_t)n_devices, GFAL_OK);
         std::vector<std::string> errs((size_t)n_devices);
+        // GFALIGN_DEDUP=1: identical alignments collapsed into weighted lanes (same
+        // output, less work when the GAF repeats the same node paths)
+        const bool dedup = getenv("GFALIGN_DEDUP") != nullptr && atoi(getenv("GFALIGN_DEDUP")) != 0;
         auto make = [&](int d) {
-            rcs[(size_t)d] = gfal_scorer_create_sharded(
+            rcs[(size_t)d] = (dedup ? gfal_scorer_create_dedup : gfal_scorer_create_sharded)(
                 a.off.data(), a.steps.data(), n_aln_, n_nodes,
                 share_device ? first_device : first_device + d, universe.data(),
                 (int32_t)universe.size(), d, n_devices, &shards_[(size_t)d]);

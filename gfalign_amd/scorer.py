@@ -26,7 +26,7 @@ class GfalInfo(ctypes.Structure):
                 ("n_workgroups", ctypes.c_int32), ("lds_bytes", ctypes.c_int32),
                 ("dp_pairs", ctypes.c_int64), ("scan_ms", ctypes.c_float),
                 ("dp_ms", ctypes.c_float), ("total_ms", ctypes.c_float),
-                ("profiled_calls", ctypes.c_int32)]
+                ("profiled_calls", ctypes.c_int32), ("n_lanes", ctypes.c_int64)]
 
 
 # every symbol include/gfalign_scorer.h declares
@@ -40,6 +40,9 @@ EXPORTS = {
     "gfal_scorer_create_sharded": (ctypes.c_int, [_i32p, _i32p, ctypes.c_int64, ctypes.c_int32,
                                                   ctypes.c_int, _i32p, ctypes.c_int32, ctypes.c_int32,
                                                   ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p)]),
+    "gfal_scorer_create_dedup": (ctypes.c_int, [_i32p, _i32p, ctypes.c_int64, ctypes.c_int32,
+                                                ctypes.c_int, _i32p, ctypes.c_int32, ctypes.c_int32,
+                                                ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p)]),
     "gfal_scorer_create_ex": (ctypes.c_int, [_i32p, _i32p, ctypes.c_int64, ctypes.c_int32,
                                              ctypes.c_int, _i32p, ctypes.c_int32,
                                              ctypes.POINTER(ctypes.c_void_p)]),
@@ -116,16 +119,20 @@ def pack_step(node_id, orientation):
 class Scorer:
     """One shard of alignments resident on one MI355X."""
 
-    def __init__(self, aln_off, aln_steps, n_nodes, device=0, universe=None, shard=None):
+    def __init__(self, aln_off, aln_steps, n_nodes, device=0, universe=None, shard=None,
+                 dedup=False):
         """shard = (index, count): this scorer keeps its share of the alignment
-        set given in full (gfal_scorer_create_sharded)."""
+        set given in full (gfal_scorer_create_sharded).  dedup: identical
+        alignments collapsed into weighted lanes (gfal_scorer_create_dedup)."""
         self._lib = load_library()
         self._h = ctypes.c_void_p()
         aln_off, aln_steps = _i32(aln_off), _i32(aln_steps)
         self.n_aln = len(aln_off) - 1
-        if shard is not None:
+        if shard is not None or dedup:
+            shard = shard or (0, 1)
             uni = None if universe is None else _i32(universe)
-            _check(self._lib.gfal_scorer_create_sharded(
+            create = self._lib.gfal_scorer_create_dedup if dedup else self._lib.gfal_scorer_create_sharded
+            _check(create(
                 _ptr(aln_off, ctypes.c_int32), _ptr(aln_steps, ctypes.c_int32),
                 self.n_aln, int(n_nodes), int(device),
                 None if uni is None else _ptr(uni, ctypes.c_int32), 0 if uni is None else len(uni),

@@ -108,6 +108,19 @@ int gfal_scorer_create_sharded(const int32_t *aln_off, const int32_t *aln_steps,
                                const int32_t *universe, int32_t n_universe,
                                int32_t shard_index, int32_t n_shards, gfal_scorer **out);
 
+/*
+ * Same as gfal_scorer_create_sharded, with identical alignments collapsed: a
+ * GAF of reads over a tangle repeats the same few-node paths many times, and a
+ * lane of the kernels then stands for all copies with a weight.  Every result
+ * (counters, pair scores, sharding) is identical to the uncollapsed scorer's;
+ * only the work shrinks.  An algorithmic shortcut in the sense of SURVEY.md
+ * 8(d): bench.py reports it next to, never inside, the headline figure.
+ */
+int gfal_scorer_create_dedup(const int32_t *aln_off, const int32_t *aln_steps,
+                             int64_t n_aln, int32_t n_nodes, int device,
+                             const int32_t *universe, int32_t n_universe,
+                             int32_t shard_index, int32_t n_shards, gfal_scorer **out);
+
 void gfal_scorer_destroy(gfal_scorer *s);
 
 /*
@@ -173,6 +186,9 @@ typedef struct {
     float    dp_ms;          /* exact-DP kernel             made since         */
     float    total_ms;       /* whole score_device call     profiling went on  */
     int32_t  profiled_calls; /* calls in that mean (ring of 128)               */
+    int64_t  n_lanes;        /* alignments resident on the device: n_aln minus
+                                the zero-step ones, or the distinct ones of a
+                                gfal_scorer_create_dedup scorer                */
 } gfal_info;
 
 /* Record HIP events (on the caller's stream) around the kernels of each score

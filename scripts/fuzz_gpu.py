@@ -45,9 +45,14 @@ for case in range(n_cases):
     flt = rnd.random() < 0.7
     os.environ["GFAL_DP_SYS_LIMIT"] = rnd.choice(["0", "8192", "4000000000"])
     n_shards = rnd.choice([1, 1, 2, 3, 5])
+    dedup = rnd.random() < 0.4
+    if dedup and rnd.random() < 0.7:            # make duplicates worth collapsing
+        alns = [list(b) for b in alns for _ in range(rnd.choice([1, 1, 3, 9]))]
+        rnd.shuffle(alns)
+        aoff, ast = csr(alns)
     acc = [np.zeros(len(paths), np.uint64) for _ in range(3)]
     for k in range(n_shards):
-        with Scorer(aoff, ast, n_nodes, universe=universe, shard=(k, n_shards)) as sc:
+        with Scorer(aoff, ast, n_nodes, universe=universe, shard=(k, n_shards), dedup=dedup) as sc:
             for a, part in zip(acc, sc.evaluate_paths(poff, pst, flt)):
                 a += part
     exp = oracle.evaluate_paths(aoff, ast, poff, pst, flt)

@@ -222,6 +222,11 @@ def test_eval_path_appendix_c2(cli, gpu):
                        env={"GFALIGN_SHARE_DEVICE": "1"})
     assert rc == 0, err
     assert out.splitlines() == gold["stdout"]
+    rc, out, err = run(cli, ["evalPath", "-f", REF_FILES + "/random3.gfa", "-g",
+                             REF_FILES + "/random3.gaf", "-p", gold["path"]],
+                       env={"GFALIGN_DEDUP": "1"})
+    assert rc == 0, err
+    assert out.splitlines() == gold["stdout"]
 
 
 @pytest.mark.gpu
@@ -243,5 +248,10 @@ def test_search_on_a_synthetic_tangle_matches_oracle(cli, gpu, tmp_path):
     rc, out, err = run(cli, base + ["--devices", "3"], env={"GFALIGN_SHARE_DEVICE": "1"})
     assert rc == 0, err
     assert out == outs[0]
+    # identical alignments collapsed into weighted lanes, sharded or not: same bytes
+    for extra in ([], ["--devices", "2"]):
+        rc, out, err = run(cli, base + extra, env={"GFALIGN_SHARE_DEVICE": "1", "GFALIGN_DEDUP": "1"})
+        assert rc == 0, err
+        assert out == outs[0]
     assert outs[0].splitlines() == exp
     assert any(int(r.split("\t")[2]) > 0 for r in exp[:-1])   # non-zero good counters

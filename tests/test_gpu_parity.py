@@ -334,6 +334,51 @@ def test_more_shards_than_items(gpu):
         assert np.array_equal(a, e.astype(np.uint64))
 
 
+@pytest.mark.parametrize("seed", [81, 82, 83])
+def test_dedup_scorer_matches_the_oracle(gpu, seed):
+    """gfal_scorer_create_dedup: identical alignments collapsed into weighted
+    lanes.  Counters (scan and both DP kernel families), pair scores and shards
+    are those of the uncollapsed set."""
+    rnd = random.Random(seed)
+    if seed == 81:
+        base, paths = random_case(rnd, 3, 120, 30, 10, 40)       # overhang-heavy
+    else:
+        base, paths = walk_case(rnd, 25, 200, 150, 30, 20 if seed == 82 else 70)
+    alns = []
+    for b in base:                                                 # 1 .. 40 copies each
+        alns += [list(b) for _ in range(rnd.choice([1, 1, 2, 5, 40]))]
+    rnd.shuffle(alns)
+    alns[7] = []
+    aoff, ast = csr(alns)
+    poff, pst = csr(paths)
+    for flt in (True, False):
+        exp = oracle.evaluate_paths(aoff, ast, poff, pst, flt)
+        with Scorer(aoff, ast, 32, dedup=True) as sc:
+            info = sc.info()
+            assert info["n_aln"] == len(alns) and info["n_lanes"] < 0.7 * len(alns)
+            got = sc.evaluate_paths(poff, pst, flt)
+        for g, e in zip(got, exp):
+            assert np.array_equal(g, e), flt
+    # shards of a dedup scorer, with the wavefront kernels forced
+    os.environ["GFAL_DP_SYS_LIMIT"] = "4000000000"
+    try:
+        acc = [np.zeros(len(paths), np.uint64) for _ in range(3)]
+        fw = np.full(len(alns), -777, np.int32)
+        rc = np.full(len(alns), -777, np.int32)
+        for k in range(3):
+            with Scorer(aoff, ast, 32, shard=(k, 3), dedup=True) as sc:
+                for a, part in zip(acc, sc.evaluate_paths(poff, pst, True)):
+                    a += part
+                sc.pair_scores(paths[0], out=(fw, rc))
+    finally:
+        del os.environ["GFAL_DP_SYS_LIMIT"]
+    exp = oracle.evaluate_paths(aoff, ast, poff, pst, True)
+    for a, e in zip(acc, exp):
+        assert np.array_equal(a, e.astype(np.uint64))
+    ofw, orc = oracle.pair_scores(aoff, ast, paths[0])
+    assert np.array_equal(fw, ofw) and np.array_equal(rc, orc)
+
+
 def test_worklist_overflow_splits_the_batch(gpu, monkeypatch):
     """More exact-DP pairs than the worklist holds: the blocking API halves the
     batch until every piece fits (a single path always does)."""

@@ -167,3 +167,15 @@ def test_full_size_counters_equal_the_fast_cpu_checker(full, tangle):
     assert np.array_equal(bad[pick], eb)
     assert np.array_equal(good[pick], eg)
     assert np.array_equal(una[pick], eu)
+
+
+def test_dedup_scorer_gives_the_same_counters_at_full_size(full, tangle):
+    """gfal_scorer_create_dedup on the config-3 set: the same counters for the
+    whole batch from far fewer resident alignments."""
+    _, (bad, good, una) = full
+    t = tangle
+    with Scorer(t.aln_off, t.aln_steps, t.V, dedup=True) as sc:
+        info = sc.info()
+        assert info["n_aln"] == t.N and info["n_lanes"] < t.N // 2
+        b, g, u = sc.evaluate_paths(t.path_off, t.path_steps, True)
+    assert np.array_equal(b, bad) and np.array_equal(g, good) and np.array_equal(u, una)
