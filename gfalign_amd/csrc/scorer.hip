@@ -145,7 +145,8 @@ struct Items {
     int n_items;
     // per item: two local node ids (16 bits each; possibly the same) that occur in
     // EVERY alignment of the item (content-sorted items nearly always have some:
-    // their first nodes), or NO_COMMON_NODE.  If no path of a tile carries both, every lane fails the
+    // their first nodes) -- or, with COMMON_EITHER, two nodes one of which every
+    // alignment has -- or NO_COMMON_NODE.  If no path of a tile carries them, every lane fails the
     // filter for every tile path and the item is skipped for that tile without
     // loading a step -- a third of the (item, tile) visits of the config-3 batch
     const uint32_t *common;
@@ -156,6 +157,7 @@ struct Items {
     const uint32_t *weight;
 };
 constexpr uint32_t NO_COMMON_NODE = 0xFFFFFFFFu;
+constexpr uint32_t COMMON_EITHER = 0x8000u;   // Items::common: every lane has the one node OR the other
 
 // --------------------------------------------------------------------------
 // k_prep: candidate path -> lookup image (+ counter initialisation)
@@ -928,8 +930,12 @@ __global__ __launch_bounds__(SCAN_THREADS, 6) void k_scan(ScanArgs a)
         const bool mine = my_it < a.items.n_items;
         const uint4 hdr = mine ? a.items.hdr[my_it] : make_uint4(0u, 0u, NO_COMMON_NODE, 0u);
         bool keep = mine;
-        if (a.filter && mine && hdr.z != NO_COMMON_NODE)     // a tile path must carry both
-            keep = (tv.nodemask[hdr.z & 0xFFFFu] & tv.nodemask[hdr.z >> 16]) != 0u;
+        if (a.filter && mine && hdr.z != NO_COMMON_NODE) {
+            const uint32_t m1 = tv.nodemask[hdr.z & 0x7FFFu], m2 = tv.nodemask[hdr.z >> 16];
+            // every lane has both nodes: a tile path must carry both; every lane has
+            // one of the two (COMMON_EITHER): some tile path must carry one of them
+            keep = ((hdr.z & COMMON_EITHER) ? (m1 | m2) : (m1 & m2)) != 0u;
+        }
 #if defined(GFAL_ABLATE) && GFAL_ABLATE == 7      // probe: (item, tile) visits and how many the common node rejects
         if (lane == 0) {
             atomicAdd(a.status + 3, (uint32_t)__builtin_popcountll(WAVE_MASK(mine)));
@@ -2373,7 +2379,23 @@ static int create_impl(const int32_t *aln_off, const int32_t *aln_steps, int64_t
                         last_c = node;
                     }
                 }
-                item_common[it] = first_c == 0xFFFFu ? NO_COMMON_NODE : (first_c | (last_c << 16));
+                if (first_c != 0xFFFFu) {
+                    item_common[it] = first_c | (last_c << 16);          // every lane has both
+                } else {
+                    // no node in all lanes (the item straddles a change of the first
+                    // node): if the lanes start with one of two nodes, a tile path
+                    // must carry at least one of those
+                    uint32_t n_a = p0[0] >> 1, n_b = 0xFFFFu;
+                    bool two = true;
+                    for (int l = 1; l < is.cnt && two; ++l) {
+                        const uint32_t node = ls[aln_off[is.idx[l]]] >> 1;
+                        if (node == n_a || node == n_b) continue;
+                        if (n_b == 0xFFFFu) n_b = node;
+                        else two = false;
+                    }
+                    if (two)
+                        item_common[it] = n_a | COMMON_EITHER | ((n_b == 0xFFFFu ? n_a : n_b) << 16);
+                }
             }
         };
         std::vector<std::thread> pool;
