@@ -937,9 +937,12 @@ __global__ __launch_bounds__(SCAN_THREADS, 6) void k_scan(ScanArgs a)
             keep = ((hdr.z & COMMON_EITHER) ? (m1 | m2) : (m1 & m2)) != 0u;
         }
 #if defined(GFAL_ABLATE) && GFAL_ABLATE == 7      // probe: (item, tile) visits and how many the common node rejects
-        if (lane == 0) {
-            atomicAdd(a.status + 3, (uint32_t)__builtin_popcountll(WAVE_MASK(mine)));
-            atomicAdd(a.status + 2, (uint32_t)__builtin_popcountll(WAVE_MASK(mine && !keep)));
+        {
+            const lanemask seen = WAVE_MASK(mine), dropped = WAVE_MASK(mine && !keep);
+            if (lane == 0) {
+                atomicAdd(a.status + 3, (uint32_t)__builtin_popcountll(seen));
+                atomicAdd(a.status + 2, (uint32_t)__builtin_popcountll(dropped));
+            }
         }
 #endif
         for (lanemask todo = WAVE_MASK(keep); todo != 0; todo &= todo - 1) {
