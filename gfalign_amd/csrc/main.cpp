@@ -574,7 +574,14 @@ int main(int argc, char **argv)
     }
     // HIP start-up (~0.2 s) runs beside the file parsing
     std::thread warm;
-    if (o.mode == 3 || o.mode == 5) warm = std::thread([] { (void)gfal_device_count(); });
+    if (o.mode == 3 || o.mode == 5)
+        warm = std::thread([dev = o.device] {
+            // an empty scorer brings up the runtime AND the device context
+            if (gfal_device_count() <= dev) return;
+            const int32_t off0 = 0;
+            gfal_scorer *s = nullptr;
+            if (gfal_scorer_create(&off0, nullptr, 0, 1, dev, &s) == GFAL_OK) gfal_scorer_destroy(s);
+        });
     struct Joiner {
         std::thread &t;
         ~Joiner()
