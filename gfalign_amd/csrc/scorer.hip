@@ -2103,7 +2103,23 @@ static int create_impl(const int32_t *aln_off, const int32_t *aln_steps, int64_t
                 if (u != w && node_local[u] == 0 && node_local[w] == 0)
                     edges.push_back(((uint64_t)std::min(u, w) << 32) | std::max(u, w));
             }
-        std::sort(edges.begin(), edges.end());
+        if (edges.size() < ((size_t)1 << 18) || std::thread::hardware_concurrency() < 4) {
+            std::sort(edges.begin(), edges.end());
+        } else {      // four sorted quarters, merged pairwise
+            const size_t q = edges.size() / 4;
+            auto part = [&](int k) { return edges.begin() + (ptrdiff_t)(k == 4 ? edges.size() : q * (size_t)k); };
+            std::thread t1([&] { std::sort(part(1), part(2)); });
+            std::thread t2([&] { std::sort(part(2), part(3)); });
+            std::thread t3([&] { std::sort(part(3), part(4)); });
+            std::sort(part(0), part(1));
+            t1.join();
+            t2.join();
+            t3.join();
+            std::thread tm([&] { std::inplace_merge(part(2), part(3), part(4)); });
+            std::inplace_merge(part(0), part(1), part(2));
+            tm.join();
+            std::inplace_merge(part(0), part(2), part(4));
+        }
         struct Nb { uint32_t to, weight; };
         std::vector<uint32_t> deg((size_t)n_nodes + 1, 0);
         std::vector<std::pair<uint64_t, uint32_t>> uniq;     // edge, multiplicity
