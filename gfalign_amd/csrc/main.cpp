@@ -41,7 +41,47 @@ struct Options {
     int return_all_paths = 0, cmd_flag = 0, stats_flag = 0, sort_alignment = 0;
     int terminal_alignments = 0;
     int device = 0, n_devices = 1;
+    unsigned threads = 0;            // -j: host threads of the file readers (0 = default)
 };
+
+#ifndef GFAL_BUILD_ID
+#define GFAL_BUILD_ID "unstamped"
+#endif
+
+// `-f -` / `-g -`: the reference reads that input from stdin (src/main.cpp:
+// 425-429, gfalibs StreamObj).  The readers here map files, so the pipe is
+// spooled to a temporary file first (removed at exit).
+std::vector<std::string> g_spooled;
+void remove_spooled()
+{
+    for (auto &f : g_spooled) unlink(f.c_str());
+}
+std::string spool_stdin()
+{
+    char name[] = "/tmp/gfalign-stdin-XXXXXX";
+    int fd = mkstemp(name);
+    if (fd < 0) {
+        fprintf(stderr, "Error: cannot create a temporary file for the piped input\n");
+        exit(EXIT_FAILURE);
+    }
+    if (g_spooled.empty()) atexit(remove_spooled);
+    g_spooled.push_back(name);
+    char buf[1 << 16];
+    ssize_t got;
+    while ((got = read(STDIN_FILENO, buf, sizeof buf)) > 0) {
+        ssize_t off = 0;
+        while (off < got) {
+            ssize_t w = write(fd, buf + off, (size_t)(got - off));
+            if (w <= 0) {
+                fprintf(stderr, "Error: cannot spool the piped input\n");
+                exit(EXIT_FAILURE);
+            }
+            off += w;
+        }
+    }
+    close(fd);
+    return name;
+}
 
 int verbose_flag = 0;
 
@@ -483,6 +523,17 @@ int main(int argc, char **argv)
     if (argc == 1) print_help();
     Options o;
     const std::string tool = argv[1];
+    if (tool == "--build-id") {    // hash of the sources this binary was built from (build.py)
+        printf("%s\n", GFAL_BUILD_ID);
+        return 0;
+    }
+    // the scorer library is loaded at run time: refuse one with another ABI
+    // (gfal_info layout) instead of letting it write past our structs
+    if (gfal_abi_version() != GFAL_ABI_VERSION) {
+        fprintf(stderr, "Error: libgfalign_scorer.so has ABI %d, this binary was built for %d\n",
+                gfal_abi_version(), GFAL_ABI_VERSION);
+        return EXIT_FAILURE;
+    }
     if (tool == "evalGFA") o.mode = 1;
     else if (tool == "search") o.mode = 3;
     else if (tool == "filter") o.mode = 4;
@@ -527,14 +578,20 @@ int main(int argc, char **argv)
     while ((c = getopt_long(argc, argv, "-:d:f:g:j:m:n:o:p:s:vh", long_options, &idx)) != -1) {
         switch (c) {
         case 'd': o.destination = optarg; break;
-        case 'f': require_file(optarg); o.gfa = optarg; break;
-        case 'g': require_file(optarg); o.gaf = optarg; break;
+        case 'f':
+            if (!strcmp(optarg, "-")) o.gfa = spool_stdin();      // main.cpp:425-429, 443-449
+            else { require_file(optarg); o.gfa = optarg; }
+            break;
+        case 'g':
+            if (!strcmp(optarg, "-")) o.gaf = spool_stdin();      // main.cpp:450-458
+            else { require_file(optarg); o.gaf = optarg; }
+            break;
         case 'm': o.max_steps = (uint32_t)atoi(optarg); break;   // main.cpp:462-464 (atoi)
         case 'n': require_file(optarg); o.node_file = optarg; break;
         case 'o': o.out_file = optarg; break;
         case 'p': o.path = optarg; break;
         case 's': o.source = optarg; break;
-        case 'j': break;
+        case 'j': o.threads = (unsigned)std::max(0, atoi(optarg)); break;   // main.cpp:472-474
         case 1: o.min_nodes = (uint32_t)atoi(optarg); break;
         case 2: o.device = atoi(optarg); break;
         case 3: o.n_devices = std::max(1, atoi(optarg)); break;
@@ -565,6 +622,12 @@ int main(int argc, char **argv)
         printf("\n");
     }
 
+    if (o.stats_flag) {
+        // gfalibs' Report::reportStats (the gfastats summary): its source is not in
+        // the reference tree, so the flag is refused, not ignored
+        fprintf(stderr, "--graph-statistics is not part of this build (see DESIGN.md).\n");
+        return EXIT_FAILURE;
+    }
     const double t_start = gfal::now_s();
     Graph g;
     std::string err;
@@ -595,12 +658,12 @@ int main(int argc, char **argv)
     PackedAlignments packed;
     if (!o.gaf.empty() && o.mode == 3) {
         // search only needs the path column (src/eval.cpp:123)
-        if (!read_gaf_paths(o.gaf, g, packed.off, packed.steps, err)) {
+        if (!read_gaf_paths(o.gaf, g, packed.off, packed.steps, err, o.threads)) {
             fprintf(stderr, "Error: %s\n", err.c_str());
             return EXIT_FAILURE;
         }
     } else if (!o.gaf.empty()) {
-        if (!read_gaf(o.gaf, recs, err)) {
+        if (!read_gaf(o.gaf, recs, err, o.threads)) {
             fprintf(stderr, "Error: %s\n", err.c_str());
             return EXIT_FAILURE;
         }
@@ -611,15 +674,16 @@ int main(int argc, char **argv)
     case 1: return run_eval_gfa(o, g, recs, totals);
     case 3: {
         const double t_read = gfal::now_s();
-        if (!g.ids.count(o.source) || !g.ids.count(o.destination)) {
-            // the reference would alias an unknown name to uId 0; refuse instead
-            fprintf(stderr, "Error: source or destination not in graph.\n");
+        if (g.headers.empty()) {
+            fprintf(stderr, "Error: the graph has no segments.\n");
             return EXIT_FAILURE;
         }
         // nodes the search can step on: the node list (include/nodetable.h:16-43)
-        // plus source and destination (src/eval.cpp:127-128)
-        std::vector<int32_t> universe{(int32_t)g.ids.at(o.source),
-                                      (int32_t)g.ids.at(o.destination)};
+        // plus source and destination (src/eval.cpp:127-128; a name that is not in
+        // the graph becomes uId 0 there -- headersToIds[source] default-inserts --
+        // and does so here)
+        std::vector<int32_t> universe{(int32_t)g.id_or_zero(o.source),
+                                      (int32_t)g.id_or_zero(o.destination)};
         {
             std::ifstream nf(o.node_file);
             std::string line;

@@ -36,6 +36,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <new>
 #include <thread>
 #include <vector>
@@ -86,6 +87,26 @@ void set_err(const char *fmt, ...)
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+// Nothing may throw across the C ABI (std::vector / std::thread on the host
+// side of create and pair_scores can): every entry point that allocates runs
+// inside this.
+template <typename F>
+int no_throw(F &&body)
+{
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        set_err("out of host memory");
+        return GFAL_E_NOMEM;
+    } catch (const std::exception &e) {
+        set_err("host error: %s", e.what());
+        return GFAL_E_NOMEM;
+    } catch (...) {
+        set_err("host error");
+        return GFAL_E_NOMEM;
+    }
 }
 
 #define HIP_TRY(expr)                                                          \
@@ -408,7 +429,7 @@ struct ScanArgs {
     int filter;
     uint32_t *counts;         // bad[P] | good[P] | unaligned[P]
     unsigned long long *worklist;
-    uint32_t *wl_count;
+    unsigned long long *wl_count;   // 64-bit: attempted appends (may exceed the capacity)
     uint32_t wl_capacity;
     uint32_t *wl_hist;        // [N_CLASSES * n_paths] entries per (length class, path)
     uint32_t *status;
@@ -454,16 +475,17 @@ __device__ __forceinline__ void push_pairs(const ScanArgs &a, bool fw, bool rc, 
 #if defined(GFAL_ABLATE) && GFAL_ABLATE == 5      // timing probe: what do the appends cost?
     return;
 #endif
-    uint32_t base = 0;
+    unsigned long long base = 0;
     int leader = __ffsll((long long)m) - 1;
     if (lane == leader) {
         const uint32_t cnt = (uint32_t)__popcll(m);
-        base = atomicAdd(a.wl_count, cnt);
+        base = atomicAdd(a.wl_count, (unsigned long long)cnt);
         atomicAdd(&a.wl_hist[(uint32_t)length_class(M) * (uint32_t)a.n_paths + path_global], cnt);
     }
-    base = __shfl(base, leader, WAVE);
+    base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(base >> 32), leader) << 32) |
+           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)base, leader);
     if (want) {
-        uint32_t idx = base + lanes_below(m, lane);
+        const unsigned long long idx = base + lanes_below(m, lane);
         if (idx < a.wl_capacity)
             a.worklist[idx] = (fw ? WL_FW : 0ull) | (rc ? WL_RC : 0ull) |
                               ((unsigned long long)path_global << 32) | slot;
@@ -736,7 +758,7 @@ __device__ __forceinline__ void scan_item(const ScanArgs &a, const TileView &tv,
         cv.nm = (uint32_t)a.L.nm;
         cv.n = n;
 #if defined(GFAL_ABLATE) && GFAL_ABLATE == 4
-        cv.dbg = a.status + 2;
+        cv.dbg = a.status + 4;
 #endif
 #if defined(GFAL_ABLATE) && GFAL_ABLATE == 2
         count(p, in_m, 0);
@@ -940,8 +962,8 @@ __global__ __launch_bounds__(SCAN_THREADS, 6) void k_scan(ScanArgs a)
         {
             const lanemask seen = WAVE_MASK(mine), dropped = WAVE_MASK(mine && !keep);
             if (lane == 0) {
-                atomicAdd(a.status + 3, (uint32_t)__builtin_popcountll(seen));
-                atomicAdd(a.status + 2, (uint32_t)__builtin_popcountll(dropped));
+                atomicAdd(a.status + 5, (uint32_t)__builtin_popcountll(seen));
+                atomicAdd(a.status + 4, (uint32_t)__builtin_popcountll(dropped));
             }
         }
 #endif
@@ -1289,7 +1311,7 @@ __global__ __launch_bounds__(1024) void k_wl_offsets(const uint32_t *__restrict_
 
 __global__ __launch_bounds__(256) void k_wl_scatter(
     Items items, const unsigned long long *__restrict__ worklist,
-    const uint32_t *__restrict__ wl_count, uint32_t wl_capacity,
+    const unsigned long long *__restrict__ wl_count, uint32_t wl_capacity,
     const uint32_t *__restrict__ offsets, uint32_t *__restrict__ cursor,
     uint32_t n_paths, unsigned long long *__restrict__ sorted,
     const uint32_t *__restrict__ class_total, uint32_t *__restrict__ class_lo)
@@ -1298,7 +1320,7 @@ __global__ __launch_bounds__(256) void k_wl_scatter(
     // were never stored, so offsets do not describe the list; the call fails
     // with GFAL_E_NOMEM and nothing downstream may touch the list
     if (*wl_count > wl_capacity) return;
-    const uint32_t total = *wl_count;
+    const uint32_t total = (uint32_t)*wl_count;
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t lane = threadIdx.x & (WAVE - 1);
     // where the classes start: prefix of the class totals (k_wl_offsets); the
@@ -1358,7 +1380,7 @@ struct DpArgs {
     int n_paths;
     const unsigned long long *sorted;
     const uint32_t *class_lo;   // [N_CLASSES + 1] ranges of the sorted list
-    const uint32_t *wl_count;
+    const unsigned long long *wl_count;
     uint32_t wl_capacity;
     uint32_t sys_limit;         // see wavefront_class()
     uint32_t *row_scratch;
@@ -1450,7 +1472,7 @@ __global__ __launch_bounds__(DP_THREADS) void k_dp_regs(DpArgs a)
     constexpr int STAGED_PATHS = 4;
     __shared__ uint16_t path_lds[STAGED_PATHS][GFAL_MAX_STEPS + 8];
     if (*a.wl_count > a.wl_capacity) return;     // overflow: see k_wl_scatter
-    const uint32_t total = *a.wl_count;
+    const uint32_t total = (uint32_t)*a.wl_count;
     if (wavefront_class(a, total, CLS)) return;   // few entries: k_dp_sys has the lower latency
     uint32_t lo, hi;
     class_range(a.class_lo, CLS, total, lo, hi);
@@ -1575,7 +1597,7 @@ __global__ __launch_bounds__(DP_THREADS) void k_dp_sys(DpArgs a)
     __shared__ uint32_t rowmark[ENTRIES][ROW_WORDS + 2];  // rows whose node occurs in B
     __shared__ uint32_t rowsel[ENTRIES][ROW_WORDS + 2];   // rows to compute
     if (*a.wl_count > a.wl_capacity) return;              // overflow: see k_wl_scatter
-    const uint32_t total = *a.wl_count;
+    const uint32_t total = (uint32_t)*a.wl_count;
     // MC = 4, 8, 16: classes 0, 1, 2; MC = 64: class 3 and the entries of the last
     // class that fit (k_dp_long skips those on a short list)
     constexpr int CLS = MC == 4 ? 0 : MC == 8 ? 1 : MC == 16 ? 2 : 3;
@@ -1738,7 +1760,7 @@ __global__ __launch_bounds__(DP_THREADS) void k_dp_long(DpArgs a)
     int stride;
     uint32_t *row = dp_row<ROWS_IN_LDS>(a.row_scratch, stride);
     if (*a.wl_count > a.wl_capacity) return;     // overflow: see k_wl_scatter
-    const uint32_t total = *a.wl_count;
+    const uint32_t total = (uint32_t)*a.wl_count;
     uint32_t lo, hi;
     class_range(a.class_lo, LONG_CLASS, total, lo, hi);
     const uint32_t n_threads = gridDim.x * DP_THREADS;
@@ -1821,7 +1843,7 @@ struct gfal_scorer {
     int64_t n_lanes = 0;                 // alignments resident on the device (distinct ones if dedup)
     std::vector<int32_t> rep_of;         // dedup: caller's alignment -> the identical one that is resident
     int32_t *d_slot_orig = nullptr;    // [n_items*64] original index or -1
-    uint32_t *d_status = nullptr;      // [4]: status word, worklist count, 2 debug words
+    uint32_t *d_status = nullptr;      // [8]: status flags, pad, worklist count (64 bit), 4 debug words
     unsigned long long *d_worklist = nullptr;   // as pushed by k_scan
     unsigned long long *d_worklist_sorted = nullptr;
     uint32_t wl_capacity = 0;
@@ -1856,6 +1878,9 @@ struct gfal_scorer {
     // bound by the latency of its longest single fill, not by throughput
     hipStream_t dp_stream[3] = {nullptr, nullptr, nullptr};
     hipEvent_t dp_fork = nullptr, dp_join[3] = {nullptr, nullptr, nullptr};
+
+    int64_t n_score_calls = 0, n_device_passes = 0, n_overflow_reruns = 0;
+    hipEvent_t order_ev = nullptr;     // orders a call behind the previous one on another stream
 
     // last call
     hipStream_t last_stream = nullptr;
@@ -1930,6 +1955,7 @@ void free_scorer(gfal_scorer *s)
     for (hipStream_t x : s->dp_stream)
         if (x) (void)hipStreamDestroy(x);
     if (s->dp_fork) (void)hipEventDestroy(s->dp_fork);
+    if (s->order_ev) (void)hipEventDestroy(s->order_ev);
     for (hipEvent_t e : s->dp_join)
         if (e) (void)hipEventDestroy(e);
     delete s;
@@ -1953,6 +1979,11 @@ size_t row_scratch_words(int max_aln_len)
 extern "C" {
 
 int gfal_abi_version(void) { return GFAL_ABI_VERSION; }
+
+#ifndef GFAL_BUILD_ID
+#define GFAL_BUILD_ID "unstamped"
+#endif
+const char *gfal_build_id(void) { return GFAL_BUILD_ID; }
 
 const char *gfal_strerror(int code)
 {
@@ -2005,8 +2036,10 @@ int gfal_scorer_create_sharded(const int32_t *aln_off, const int32_t *aln_steps,
                                const int32_t *universe, int32_t n_universe,
                                int32_t shard_index, int32_t n_shards, gfal_scorer **out)
 {
-    return create_impl(aln_off, aln_steps, n_aln, n_nodes, device, universe, n_universe,
-                       shard_index, n_shards, false, out);
+    return no_throw([&] {
+        return create_impl(aln_off, aln_steps, n_aln, n_nodes, device, universe, n_universe,
+                           shard_index, n_shards, false, out);
+    });
 }
 
 int gfal_scorer_create_dedup(const int32_t *aln_off, const int32_t *aln_steps,
@@ -2014,8 +2047,10 @@ int gfal_scorer_create_dedup(const int32_t *aln_off, const int32_t *aln_steps,
                              const int32_t *universe, int32_t n_universe,
                              int32_t shard_index, int32_t n_shards, gfal_scorer **out)
 {
-    return create_impl(aln_off, aln_steps, n_aln, n_nodes, device, universe, n_universe,
-                       shard_index, n_shards, true, out);
+    return no_throw([&] {
+        return create_impl(aln_off, aln_steps, n_aln, n_nodes, device, universe, n_universe,
+                           shard_index, n_shards, true, out);
+    });
 }
 
 static int create_impl(const int32_t *aln_off, const int32_t *aln_steps, int64_t n_aln,
@@ -2453,7 +2488,12 @@ static int create_impl(const int32_t *aln_off, const int32_t *aln_steps, int64_t
     s->n_item_u16 = (int64_t)item_steps.size();
 
     int rc = GFAL_OK;
+    struct Guard {      // an exception below must not leak the device buffers
+        gfal_scorer *s;
+        ~Guard() { if (s) free_scorer(s); }
+    } guard{s};
     auto fail = [&](int code) {
+        guard.s = nullptr;
         free_scorer(s);
         return code;
     };
@@ -2470,6 +2510,7 @@ static int create_impl(const int32_t *aln_off, const int32_t *aln_steps, int64_t
     CREATE_TRY(hipDeviceGetAttribute(&s->n_cus, hipDeviceAttributeMultiprocessorCount, device));
     CREATE_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     CREATE_TRY(hipEventCreateWithFlags(&s->dp_fork, hipEventDisableTiming));
+    CREATE_TRY(hipEventCreateWithFlags(&s->order_ev, hipEventDisableTiming));
     for (int i = 0; i < 3; ++i) {
         CREATE_TRY(hipStreamCreateWithFlags(&s->dp_stream[i], hipStreamNonBlocking));
         CREATE_TRY(hipEventCreateWithFlags(&s->dp_join[i], hipEventDisableTiming));
@@ -2501,8 +2542,8 @@ static int create_impl(const int32_t *aln_off, const int32_t *aln_steps, int64_t
     if ((rc = dev_upload(&s->d_slot_orig, slot_orig))) return fail(rc);
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_len_bins),
                          3 * LEN_BINS * sizeof(uint32_t)));
-    CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_status), 4 * sizeof(uint32_t)));
-    CREATE_TRY(hipMemset(s->d_status, 0, 4 * sizeof(uint32_t)));
+    CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_status), 8 * sizeof(uint32_t)));
+    CREATE_TRY(hipMemset(s->d_status, 0, 8 * sizeof(uint32_t)));
     // worklist: at least one entry per alignment, so a single path always fits
     if (const char *env = getenv("GFAL_DP_SYS_LIMIT")) s->dp_sys_limit = (uint32_t)atoll(env);
     if (const char *env = getenv("GFAL_GRAPHS")) s->use_graphs = atoi(env) != 0;
@@ -2518,6 +2559,7 @@ static int create_impl(const int32_t *aln_off, const int32_t *aln_steps, int64_t
 
 #undef CREATE_TRY
     mark("device upload");
+    guard.s = nullptr;
     *out = s;
     return GFAL_OK;
 }
@@ -2535,6 +2577,40 @@ int gfal_scorer_set_profiling(gfal_scorer *s, int enable)
     }
     s->profiling = enable != 0;
     s->ev_calls = 0;
+    return GFAL_OK;
+}
+
+// Worklist entries the blocking API may grow to on its own (two lists of 8 bytes
+// per entry: 2 x 8 GiB); beyond that a batch is split instead.
+constexpr unsigned long long WL_MAX_ENTRIES = 1ull << 30;
+
+// Make room for `need` exact-DP pairs per call (+25 %).  The streams that used
+// the old lists must be idle.
+static int grow_worklist(gfal_scorer *s, unsigned long long need)
+{
+    unsigned long long want = need + need / 4 + 1024;
+    if (want > WL_MAX_ENTRIES) want = WL_MAX_ENTRIES;
+    if (want <= s->wl_capacity) return GFAL_OK;
+    if (need > want) {
+        set_err("exact-DP worklist: %llu pairs in one batch exceed the %llu-entry limit: split the batch",
+                need, WL_MAX_ENTRIES);
+        return GFAL_E_NOMEM;
+    }
+    HIP_TRY(hipSetDevice(s->device));
+    if (s->have_last) HIP_TRY(hipStreamSynchronize(s->last_stream));
+    unsigned long long *a = nullptr, *b = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&a), (size_t)want * sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&b), (size_t)want * sizeof(unsigned long long)) != hipSuccess) {
+        if (a) (void)hipFree(a);
+        (void)hipGetLastError();
+        set_err("exact-DP worklist: cannot allocate %llu entries", want);
+        return GFAL_E_NOMEM;
+    }
+    (void)hipFree(s->d_worklist);
+    (void)hipFree(s->d_worklist_sorted);
+    s->d_worklist = a;
+    s->d_worklist_sorted = b;
+    s->wl_capacity = (uint32_t)want;
     return GFAL_OK;
 }
 
@@ -2572,6 +2648,13 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
     if (max_path_len < 1 || max_path_len > GFAL_MAX_STEPS) return GFAL_E_RANGE;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     HIP_TRY(hipSetDevice(s->device));
+    // the per-call buffers (images, worklists, bins, status) are shared by all
+    // calls on this scorer: a call on another stream waits for the previous one
+    if (s->have_last && s->last_stream != st) {
+        HIP_TRY(hipEventRecord(s->order_ev, s->last_stream));
+        HIP_TRY(hipStreamWaitEvent(st, s->order_ev, 0));
+    }
+    ++s->n_device_passes;
 
     const ImageLayout L = make_layout(s->n_local, max_path_len);
     const size_t img_bytes = (size_t)L.total * sizeof(uint16_t);
@@ -2591,7 +2674,7 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
     // status words by k_len_sort_block
     const bool one_block_sort = n_paths <= 32768;
     if (!one_block_sort) {
-        HIP_TRY(hipMemsetAsync(s->d_status, 0, 4 * sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(s->d_status, 0, 8 * sizeof(uint32_t), st));
     }
     hipEvent_t *ev = s->ev[s->ev_calls % gfal_scorer::EV_RING];
     if (s->profiling) HIP_TRY(hipEventRecord(ev[0], st));
@@ -2604,7 +2687,7 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
     d_counts = s->d_counts_slot;
     if (one_block_sort) {
         hipLaunchKernelGGL(k_len_sort_block, dim3(1), dim3(LEN_BINS), 0, st, d_path_off,
-                           (int)n_paths, s->d_order, s->d_status, 4, nullptr, 0);
+                           (int)n_paths, s->d_order, s->d_status, 8, nullptr, 0);
     } else {
         HIP_TRY(hipMemsetAsync(s->d_len_bins, 0, LEN_BINS * sizeof(uint32_t), st));
         hipLaunchKernelGGL(k_len_hist, dim3(p_blocks), dim3(256), 0, st, d_path_off,
@@ -2665,7 +2748,7 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
         a.filter = filter ? 1 : 0;
         a.counts = d_counts;
         a.worklist = s->d_worklist;
-        a.wl_count = s->d_status + 1;
+        a.wl_count = reinterpret_cast<unsigned long long *>(s->d_status + 2);
         a.wl_capacity = s->wl_capacity;
         a.wl_hist = d_hist;
         a.status = s->d_status;
@@ -2685,7 +2768,7 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
         hipLaunchKernelGGL(k_wl_offsets, dim3(N_CLASSES), dim3(1024), 0, st, d_hist, d_offsets,
                            d_cursor, d_class_lo + 8, (int)n_paths);
         hipLaunchKernelGGL(k_wl_scatter, dim3(256), dim3(256), 0, st, a.items,
-                           s->d_worklist, s->d_status + 1, s->wl_capacity, d_offsets,
+                           s->d_worklist, a.wl_count, s->wl_capacity, d_offsets,
                            d_cursor, (uint32_t)n_paths, s->d_worklist_sorted, d_class_lo + 8, d_class_lo);
         DpArgs d;
         d.items = a.items;
@@ -2694,7 +2777,7 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
         d.n_paths = n_paths;
         d.sorted = s->d_worklist_sorted;
         d.class_lo = d_class_lo;
-        d.wl_count = s->d_status + 1;
+        d.wl_count = a.wl_count;
         d.wl_capacity = s->wl_capacity;
         d.sys_limit = s->dp_sys_limit;
         d.row_scratch = s->d_rows;
@@ -2761,8 +2844,10 @@ int gfal_scorer_score_device(gfal_scorer *s, const int32_t *d_path_off,
                              int64_t total_steps, int32_t max_path_len, int filter,
                              uint32_t *d_counts, void *hip_stream)
 {
-    return score_device_impl(s, d_path_off, d_path_steps, n_paths, total_steps, max_path_len,
-                             filter, d_counts, hip_stream, nullptr);
+    return no_throw([&] {
+        return score_device_impl(s, d_path_off, d_path_steps, n_paths, total_steps, max_path_len,
+                                 filter, d_counts, hip_stream, nullptr);
+    });
 }
 
 // status words of a finished run -> return code
@@ -2773,8 +2858,8 @@ static int status_to_code(const gfal_scorer *s, const uint32_t *host)
         return GFAL_E_RANGE;
     }
     if (host[0] & ST_DP_OVERFLOW) {
-        set_err("exact-DP worklist overflow (%u pairs, capacity %u): split the batch",
-                host[1], s->wl_capacity);
+        set_err("exact-DP worklist overflow (%llu pairs, capacity %u)",
+                (unsigned long long)host[2] | ((unsigned long long)host[3] << 32), s->wl_capacity);
         return GFAL_E_NOMEM;
     }
     return GFAL_OK;
@@ -2785,11 +2870,21 @@ int gfal_scorer_sync_status(gfal_scorer *s)
     if (!s) return GFAL_E_ARG;
     if (!s->have_last) return GFAL_OK;
     HIP_TRY(hipSetDevice(s->device));
-    uint32_t host[2] = {0, 0};
+    uint32_t host[4] = {0, 0, 0, 0};
     HIP_TRY(hipMemcpyAsync(host, s->d_status, sizeof(host), hipMemcpyDeviceToHost,
                            s->last_stream));
     HIP_TRY(hipStreamSynchronize(s->last_stream));
-    return status_to_code(s, host);
+    const int rc = status_to_code(s, host);
+    if (rc == GFAL_E_NOMEM) {
+        // the list was too short for this batch: make room, so that the caller's
+        // next attempt with the same batch fits (the stream is idle here)
+        const unsigned long long need = (unsigned long long)host[2] | ((unsigned long long)host[3] << 32);
+        const int grown = grow_worklist(s, need);
+        if (grown == GFAL_OK)
+            set_err("exact-DP worklist overflow (%llu pairs): the list has been grown to %u entries, "
+                    "submit the batch again", need, s->wl_capacity);
+    }
+    return rc;
 }
 
 static int score_range(gfal_scorer *s, const int32_t *path_off,
@@ -2860,8 +2955,21 @@ static int score_range(gfal_scorer *s, const int32_t *path_off,
     s->have_last = true;
     HIP_TRY(hipStreamSynchronize(s->stream));
     rc = status_to_code(s, s->h_out + (size_t)3 * P);
-    if (rc == GFAL_E_NOMEM && P > 1) {
-        // worklist overflow: halve the batch (a single path always fits)
+    if (rc == GFAL_E_NOMEM) {
+        // Worklist overflow.  The pass counted every pair it wanted to append, so
+        // the need is known exactly: grow the lists ONCE to fit (they stay that
+        // size for the scorer's lifetime, so a search pays this on the first deep
+        // batch only) and run the batch again.  Only a batch that needs more than
+        // WL_MAX_ENTRIES is split (a single path always fits: at most one entry
+        // per alignment, and the lists hold at least that).
+        const uint32_t *st4 = s->h_out + (size_t)3 * P;
+        const unsigned long long need = (unsigned long long)st4[2] | ((unsigned long long)st4[3] << 32);
+        ++s->n_overflow_reruns;
+        if (need + need / 4 + 1024 <= WL_MAX_ENTRIES && getenv("GFAL_DEBUG_WL_NO_GROW") == nullptr) {
+            if ((rc = grow_worklist(s, need))) return rc;
+            return score_range(s, path_off, path_steps, lo, hi, max_len, filter, bad, good, unaligned);
+        }
+        if (P == 1) return rc;
         int32_t mid = lo + P / 2;
         rc = score_range(s, path_off, path_steps, lo, mid, max_len, filter, bad, good,
                          unaligned);
@@ -2901,11 +3009,23 @@ int gfal_scorer_score(gfal_scorer *s, const int32_t *path_off,
         }
     }
     HIP_TRY(hipSetDevice(s->device));
-    return score_range(s, path_off, path_steps, 0, n_paths, max_len, filter, bad, good,
-                       unaligned);
+    ++s->n_score_calls;
+    return no_throw([&] {
+        return score_range(s, path_off, path_steps, 0, n_paths, max_len, filter, bad, good,
+                           unaligned);
+    });
 }
 
+static int pair_scores_impl(gfal_scorer *s, const int32_t *path_steps, int32_t n,
+                            int32_t *fw, int32_t *rc_out);
+
 int gfal_scorer_pair_scores(gfal_scorer *s, const int32_t *path_steps, int32_t n,
+                            int32_t *fw, int32_t *rc_out)
+{
+    return no_throw([&] { return pair_scores_impl(s, path_steps, n, fw, rc_out); });
+}
+
+static int pair_scores_impl(gfal_scorer *s, const int32_t *path_steps, int32_t n,
                             int32_t *fw, int32_t *rc_out)
 {
     if (!s || !path_steps || !fw || !rc_out) return GFAL_E_ARG;
@@ -2929,7 +3049,7 @@ int gfal_scorer_pair_scores(gfal_scorer *s, const int32_t *path_steps, int32_t n
     HIP_TRY(hipMemcpy(s->d_path_off, off, sizeof(off), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(s->d_path_steps, path_steps, (size_t)n * sizeof(int32_t),
                       hipMemcpyHostToDevice));
-    HIP_TRY(hipMemsetAsync(s->d_status, 0, 2 * sizeof(uint32_t), s->stream));
+    HIP_TRY(hipMemsetAsync(s->d_status, 0, 8 * sizeof(uint32_t), s->stream));
     const size_t prep_lds = img_bytes + (size_t)L.nm * sizeof(uint16_t) +
                             (size_t)L.v2 * sizeof(uint32_t);
     hipLaunchKernelGGL(k_prep, dim3(1), dim3(PREP_THREADS), prep_lds, s->stream, s->d_path_off,
@@ -3008,18 +3128,22 @@ int gfal_scorer_get_info(gfal_scorer *s, gfal_info *out)
     out->n_workgroups = s->last_grid;
     out->lds_bytes = s->last_lds;
     out->n_lanes = s->n_lanes;
+    out->n_score_calls = s->n_score_calls;
+    out->n_device_passes = s->n_device_passes;
+    out->n_overflow_reruns = s->n_overflow_reruns;
+    out->wl_capacity = s->wl_capacity;
     if (s->have_last) {
         HIP_TRY(hipSetDevice(s->device));
-        uint32_t host[4] = {0, 0, 0, 0};
+        uint32_t host[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         HIP_TRY(hipMemcpyAsync(host, s->d_status, sizeof(host), hipMemcpyDeviceToHost,
                                s->last_stream));
         HIP_TRY(hipStreamSynchronize(s->last_stream));
-        out->dp_pairs = host[1];
+        out->dp_pairs = (int64_t)((unsigned long long)host[2] | ((unsigned long long)host[3] << 32));
 #if defined(GFAL_ABLATE) && GFAL_ABLATE == 4
-        fprintf(stderr, "chain-loop iterations %u, with a wave-uniform entry %u\n", host[2], host[3]);
+        fprintf(stderr, "chain-loop iterations %u, with a wave-uniform entry %u\n", host[4], host[5]);
 #endif
 #if defined(GFAL_ABLATE) && GFAL_ABLATE == 7
-        fprintf(stderr, "(item, tile) visits %u, rejected through the common node %u\n", host[3], host[2]);
+        fprintf(stderr, "(item, tile) visits %u, rejected through the common node %u\n", host[5], host[4]);
 #endif
         if (s->profiling && s->ev_calls > 0) {
             const int n = std::min(s->ev_calls, (int)gfal_scorer::EV_RING);

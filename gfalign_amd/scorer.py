@@ -26,12 +26,15 @@ class GfalInfo(ctypes.Structure):
                 ("n_workgroups", ctypes.c_int32), ("lds_bytes", ctypes.c_int32),
                 ("dp_pairs", ctypes.c_int64), ("scan_ms", ctypes.c_float),
                 ("dp_ms", ctypes.c_float), ("total_ms", ctypes.c_float),
-                ("profiled_calls", ctypes.c_int32), ("n_lanes", ctypes.c_int64)]
+                ("profiled_calls", ctypes.c_int32), ("n_lanes", ctypes.c_int64),
+                ("n_score_calls", ctypes.c_int64), ("n_device_passes", ctypes.c_int64),
+                ("n_overflow_reruns", ctypes.c_int64), ("wl_capacity", ctypes.c_int64)]
 
 
 # every symbol include/gfalign_scorer.h declares
 EXPORTS = {
     "gfal_abi_version": (ctypes.c_int, []),
+    "gfal_build_id": (ctypes.c_char_p, []),
     "gfal_strerror": (ctypes.c_char_p, [ctypes.c_int]),
     "gfal_last_error": (ctypes.c_char_p, []),
     "gfal_device_count": (ctypes.c_int, []),

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define GFAL_ABI_VERSION 1
+#define GFAL_ABI_VERSION 2
 
 /* include/alignments.h:246 (MAX_N 1001): longest path / alignment accepted. */
 #define GFAL_MAX_STEPS 1000
@@ -60,6 +60,10 @@ typedef struct {
 } gfal_stats;
 
 int         gfal_abi_version(void);
+/* Hash of the sources and flags this library was compiled from (set by
+   gfalign_amd/build.py; "unstamped" for a hand build): lets a caller or a test
+   prove that the binary it loaded matches the source tree next to it. */
+const char *gfal_build_id(void);
 const char *gfal_strerror(int code);
 /* Text of the last failure on this thread (HIP error string and call site). */
 const char *gfal_last_error(void);
@@ -189,6 +193,15 @@ typedef struct {
     int64_t  n_lanes;        /* alignments resident on the device: n_aln minus
                                 the zero-step ones, or the distinct ones of a
                                 gfal_scorer_create_dedup scorer                */
+    int64_t  n_score_calls;  /* gfal_scorer_score calls since create           */
+    int64_t  n_device_passes;/* score passes enqueued since create (one per
+                                score_device call; a blocking call that ran out
+                                of worklist adds one per re-run piece)         */
+    int64_t  n_overflow_reruns; /* blocking calls whose batch had to be run
+                                again because the exact-DP worklist was too
+                                short (the list grows to fit: once per scorer
+                                and batch shape)                               */
+    int64_t  wl_capacity;    /* exact-DP worklist entries (grows on overflow)  */
 } gfal_info;
 
 /* Record HIP events (on the caller's stream) around the kernels of each score

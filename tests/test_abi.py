@@ -35,9 +35,19 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_abi_version_and_strerror(lib):
-    assert lib.gfal_abi_version() == 1
+    assert lib.gfal_abi_version() == 2
     assert lib.gfal_strerror(0) == b"ok"
     assert b"device" in lib.gfal_strerror(-3)
+
+
+def test_binary_matches_the_sources(lib):
+    """build.py stamps every artefact with the hash of its sources: the library
+    that loads here (and travels to the GPU box) is the one HEAD describes."""
+    assert lib.gfal_build_id().decode() == gbuild.scorer_build_id()
+    cli = gbuild.build_cli()
+    import subprocess
+    out = subprocess.run([cli, "--build-id"], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip() == gbuild.cli_build_id()
 
 
 def test_argument_validation_needs_no_device(lib):

@@ -255,3 +255,47 @@ def test_search_on_a_synthetic_tangle_matches_oracle(cli, gpu, tmp_path):
         assert out == outs[0]
     assert outs[0].splitlines() == exp
     assert any(int(r.split("\t")[2]) > 0 for r in exp[:-1])   # non-zero good counters
+
+
+# ---- CLI behaviours of the reference beyond its .tst files (CPU) ----
+
+def test_graph_statistics_is_refused_not_ignored(cli):
+    """validateFiles/test.1.tst / test.4.tst need gfalibs' gfastats report, which
+    is not in the reference tree: the flag fails loudly instead of printing a
+    summary without the '+++Assembly summary+++' block."""
+    rc, out, err = run(cli, ["evalGFA", "-f", REF_FILES + "/random1.gfa", "-g",
+                             REF_FILES + "/random1.gaf", "--graph-statistics"])
+    assert rc != 0 and out == "" and "not part of this build" in err
+
+
+def test_piped_gfa_input(cli):
+    """`-f -` reads the graph from stdin (reference src/main.cpp:425-429, 443-449)."""
+    args, expected = tst("test.6.tst")
+    args = [a.replace("testFiles/", REF_FILES + "/") for a in args]
+    gfa = args[args.index("-f") + 1]
+    args[args.index("-f") + 1] = "-"
+    with open(gfa, "rb") as f:
+        p = subprocess.run([cli] + args, stdin=f, capture_output=True, timeout=120)
+    assert p.returncode == 0 and p.stdout.decode() == expected
+
+
+def test_unknown_source_aliases_node_zero(cli):
+    """reference src/eval.cpp:127-128: headersToIds[source] default-inserts, so a
+    name that is not in the graph stands for uId 0 (the first S line).  random3's
+    first segment is '1': the search from 'nope' gives the rows of the search
+    from '1' (path strings come from the uIds)."""
+    args, expected = tst("test.6.tst")
+    args = [a.replace("testFiles/", REF_FILES + "/") for a in args]
+    args[args.index("-s") + 1] = "nope"
+    rc, out, _ = run(cli, args)
+    assert rc == 0 and out == expected
+
+
+def test_threads_option_is_accepted(cli, tmp_path):
+    """-j sets the reader threads (reference src/main.cpp:472-474); any value
+    gives the same bytes."""
+    args, expected = tst("test.7.tst")
+    args = [a.replace("testFiles/", REF_FILES + "/") for a in args]
+    for j in ("1", "3"):
+        rc, out, _ = run(cli, args + ["-j", j], cwd=str(tmp_path))
+        assert rc == 0 and out == expected

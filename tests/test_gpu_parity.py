@@ -9,7 +9,7 @@ import pytest
 
 import oracle
 from gfalign_amd import scorer, synth
-from gfalign_amd.scorer import GFAL_STEP_OTHER, Scorer
+from gfalign_amd.scorer import GFAL_STEP_OTHER, Scorer, ScorerError
 from helpers import (GOLDEN, csr, load_appendix_c, parse_path_string,
                      random3_alignments, random_case, walk_case)
 
@@ -32,6 +32,9 @@ def test_library_is_the_in_tree_hip_build(gpu):
     assert os.path.samefile(os.path.dirname(scorer.library_path()),
                             os.path.join(os.path.dirname(scorer.__file__), "csrc"))
     assert scorer.device_count() >= 1
+    # the binary that is loaded was compiled from the sources next to it
+    from gfalign_amd import build as gbuild
+    assert scorer.load_library().gfal_build_id().decode() == gbuild.scorer_build_id()
 
 
 def test_random3_appendix_c(gpu):
@@ -379,23 +382,78 @@ def test_dedup_scorer_matches_the_oracle(gpu, seed):
     assert np.array_equal(fw, ofw) and np.array_equal(rc, orc)
 
 
-def test_worklist_overflow_splits_the_batch(gpu, monkeypatch):
-    """More exact-DP pairs than the worklist holds: the blocking API halves the
-    batch until every piece fits (a single path always does)."""
+def test_worklist_overflow_grows_the_list_once(gpu, monkeypatch):
+    """More exact-DP pairs than the worklist holds: the blocking API grows the
+    list to the need the pass itself counted and runs the batch once more; the
+    next call on the same scorer fits without a re-run."""
     rnd = random.Random(41)
     alns, paths = random_case(rnd, 2, 2500, 64, 7, 10, min_m=2, min_n=4)
     aoff, ast = csr(alns)
     poff, pst = csr(paths)
+    exp = oracle.evaluate_paths(aoff, ast, poff, pst, True)
     monkeypatch.setenv("GFAL_DEBUG_WL_CAPACITY", "1")      # capacity = max(n_aln, 1)
     with Scorer(aoff, ast, 4) as sc:
+        assert sc.info()["wl_capacity"] == len(alns)
         got = sc.evaluate_paths(poff, pst, True)
-        assert sc.info()["dp_pairs"] <= len(alns)            # the last piece fitted
-    monkeypatch.delenv("GFAL_DEBUG_WL_CAPACITY")
+        info = sc.info()
+        assert info["dp_pairs"] > len(alns)                  # it did not fit the first list
+        assert info["n_overflow_reruns"] == 1 and info["n_device_passes"] == 2
+        assert info["wl_capacity"] >= info["dp_pairs"]
+        again = sc.evaluate_paths(poff, pst, True)
+        info = sc.info()
+        assert info["n_overflow_reruns"] == 1 and info["n_device_passes"] == 3
+        assert info["n_score_calls"] == 2
+    for g, a, x in zip(got, again, exp):
+        assert np.array_equal(g, x) and np.array_equal(a, x)
+
+
+def test_worklist_overflow_splits_the_batch(gpu, monkeypatch):
+    """A list that may not grow (GFAL_DEBUG_WL_NO_GROW; in production: a batch
+    that needs more than the 2 x 8 GiB limit): the blocking API halves the batch
+    until every piece fits (a single path always does)."""
+    rnd = random.Random(41)
+    alns, paths = random_case(rnd, 2, 2500, 64, 7, 10, min_m=2, min_n=4)
+    aoff, ast = csr(alns)
+    poff, pst = csr(paths)
+    monkeypatch.setenv("GFAL_DEBUG_WL_CAPACITY", "1")
+    monkeypatch.setenv("GFAL_DEBUG_WL_NO_GROW", "1")
     with Scorer(aoff, ast, 4) as sc:
-        sc.evaluate_paths(poff, pst, True)
-        assert sc.info()["dp_pairs"] > len(alns)             # unsplit, it would not have
+        got = sc.evaluate_paths(poff, pst, True)
+        info = sc.info()
+        assert info["dp_pairs"] <= len(alns)                 # the last piece fitted
+        assert info["wl_capacity"] == len(alns) and info["n_overflow_reruns"] >= 1
     exp = oracle.evaluate_paths(aoff, ast, poff, pst, True)
     for g, x in zip(got, exp):
+        assert np.array_equal(g, x)
+
+
+def test_device_api_reports_overflow_and_grows(gpu, monkeypatch):
+    """score_device cannot re-run by itself: sync_status reports the overflow,
+    grows the list, and the caller's second attempt fits."""
+    import torch
+    rnd = random.Random(43)
+    alns, paths = random_case(rnd, 2, 2000, 48, 7, 10, min_m=2, min_n=4)
+    aoff, ast = csr(alns)
+    poff, pst = csr(paths)
+    exp = oracle.evaluate_paths(aoff, ast, poff, pst, True)
+    monkeypatch.setenv("GFAL_DEBUG_WL_CAPACITY", "1")
+    dev = torch.device("cuda", 0)
+    d_off = torch.tensor(poff, dtype=torch.int32, device=dev)
+    d_st = torch.tensor(pst, dtype=torch.int32, device=dev)
+    d_cnt = torch.zeros(3 * len(paths), dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    with Scorer(aoff, ast, 4) as sc:
+        args = (d_off.data_ptr(), d_st.data_ptr(), len(paths), len(pst), max(len(p) for p in paths),
+                True, d_cnt.data_ptr(), stream)
+        sc.score_device(*args)
+        with pytest.raises(ScorerError) as e:
+            sc.sync_status()
+        assert e.value.code == -5 and "grown" in str(e.value)
+        sc.score_device(*args)
+        sc.sync_status()
+        counts = d_cnt.cpu().numpy().view(np.uint32)
+    P = len(paths)
+    for g, x in zip((counts[:P], counts[P:2 * P], counts[2 * P:]), exp):
         assert np.array_equal(g, x)
 
 
