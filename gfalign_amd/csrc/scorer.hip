@@ -191,7 +191,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(
     uint32_t n_empty, int filter, ImageLayout L,
     const int32_t *__restrict__ order, uint16_t *__restrict__ images,
     uint32_t *__restrict__ counts, uint32_t *__restrict__ status,
-    uint32_t *__restrict__ wl_hist)
+    uint32_t *__restrict__ wl_hist, uint16_t *__restrict__ lids_out)
 {
     extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
     uint16_t *img = smem;
@@ -300,6 +300,10 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(
     for (int i = lane * 2; i < L.total; i += PREP_THREADS * 2)
         *reinterpret_cast<uint32_t *>(dst + i) =
             *reinterpret_cast<const uint32_t *>(img + i);
+    // k_scan2 builds its node masks from the node ids along the path
+    if (lids_out)
+        for (int i = lane; i < L.nm; i += PREP_THREADS)
+            lids_out[(size_t)q * L.nm + i] = i < n ? lids[i] : (uint16_t)0xFFFFu;
 
     for (int o = 32; o > 0; o >>= 1) covered += __shfl_down(covered, o, WAVE);
     // across the waves: the chain heads are dead by now, their first word adds up
@@ -426,6 +430,7 @@ struct ScanArgs {
     int tile;                 // paths per workgroup (<= MAX_TILE)
     int n_tiles;
     int n_chunks;
+    int item_lo;              // first item this kernel scans (the ones before it: k_scan2)
     int filter;
     uint32_t *counts;         // bad[P] | good[P] | unaligned[P]
     unsigned long long *worklist;
@@ -466,8 +471,17 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long m, int lane)
 // Append the lanes in `want` to the worklist (fw / rc: which orientation has
 // the overhang) and count them in the (path, length class) histogram that the
 // counting sort in front of k_dp uses.
-__device__ __forceinline__ void push_pairs(const ScanArgs &a, bool fw, bool rc, int lane,
-                                           uint32_t path_global, uint32_t slot, int M)
+// Wave votes as 64-bit lane masks (SGPR pairs): most of the per-(wave, path)
+// bookkeeping below is scalar mask arithmetic, not per-lane code.
+using lanemask = unsigned long long;
+#define WAVE_MASK(pred) (__builtin_amdgcn_ballot_w64(pred))
+#define WAVE_ANY(pred) (__builtin_amdgcn_ballot_w64(pred) != 0ull)
+
+__device__ __forceinline__ void push_pairs_to(unsigned long long *worklist,
+                                              unsigned long long *wl_count, uint32_t wl_capacity,
+                                              uint32_t *wl_hist, uint32_t *status, int n_paths,
+                                              bool fw, bool rc, int lane, uint32_t path_global,
+                                              uint32_t slot, int M)
 {
     const bool want = fw || rc;
     unsigned long long m = __builtin_amdgcn_ballot_w64(want);
@@ -479,19 +493,68 @@ __device__ __forceinline__ void push_pairs(const ScanArgs &a, bool fw, bool rc, 
     int leader = __ffsll((long long)m) - 1;
     if (lane == leader) {
         const uint32_t cnt = (uint32_t)__popcll(m);
-        base = atomicAdd(a.wl_count, (unsigned long long)cnt);
-        atomicAdd(&a.wl_hist[(uint32_t)length_class(M) * (uint32_t)a.n_paths + path_global], cnt);
+        base = atomicAdd(wl_count, (unsigned long long)cnt);
+        atomicAdd(&wl_hist[(uint32_t)length_class(M) * (uint32_t)n_paths + path_global], cnt);
     }
     base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(base >> 32), leader) << 32) |
            (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)base, leader);
     if (want) {
         const unsigned long long idx = base + lanes_below(m, lane);
-        if (idx < a.wl_capacity)
-            a.worklist[idx] = (fw ? WL_FW : 0ull) | (rc ? WL_RC : 0ull) |
-                              ((unsigned long long)path_global << 32) | slot;
+        if (idx < wl_capacity)
+            worklist[idx] = (fw ? WL_FW : 0ull) | (rc ? WL_RC : 0ull) |
+                            ((unsigned long long)path_global << 32) | slot;
         else
-            atomicOr(a.status, ST_DP_OVERFLOW);
+            atomicOr(status, ST_DP_OVERFLOW);
     }
+}
+
+// The same for all tile paths of one item at once: bit p of fw / rc = this lane's
+// alignment is a candidate on tile path p.  One returning atomic per item (the
+// list cursor), fire-and-forget adds for the per-path histogram.
+__device__ __forceinline__ void push_item_pairs(unsigned long long *worklist,
+                                                unsigned long long *wl_count, uint32_t wl_capacity,
+                                                uint32_t *wl_hist, uint32_t *status, int n_paths,
+                                                uint32_t fw, uint32_t rc, int lane, uint32_t path0,
+                                                int tile_paths, uint32_t slot, int M)
+{
+    const uint32_t any = fw | rc;
+    if (!WAVE_ANY(any != 0u)) return;
+    const uint32_t mine = (uint32_t)__popc(any);
+    uint32_t incl = mine;                            // inclusive prefix over the lanes
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) {
+        const uint32_t v = (uint32_t)__shfl_up((int)incl, o, WAVE);
+        if (lane >= o) incl += v;
+    }
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, WAVE - 1);
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(wl_count, (unsigned long long)total);
+    base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(base >> 32), 0) << 32) |
+           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)base, 0);
+    const uint32_t cls = (uint32_t)length_class(M);
+    for (int p = 0; p < tile_paths; ++p) {
+        const lanemask m = WAVE_MASK(((any >> p) & 1u) != 0u);
+        if (m != 0 && lane == 0)
+            atomicAdd(&wl_hist[cls * (uint32_t)n_paths + path0 + (uint32_t)p], (uint32_t)__popcll(m));
+    }
+    unsigned long long idx = base + (incl - mine);
+    bool overflow = false;
+    for (uint32_t left = any; left != 0u; left &= left - 1u, ++idx) {
+        const uint32_t p = (uint32_t)__builtin_ctz(left);
+        if (idx < wl_capacity)
+            worklist[idx] = (((fw >> p) & 1u) ? WL_FW : 0ull) | (((rc >> p) & 1u) ? WL_RC : 0ull) |
+                            ((unsigned long long)(path0 + p) << 32) | slot;
+        else
+            overflow = true;
+    }
+    if (overflow) atomicOr(status, ST_DP_OVERFLOW);
+}
+
+__device__ __forceinline__ void push_pairs(const ScanArgs &a, bool fw, bool rc, int lane,
+                                           uint32_t path_global, uint32_t slot, int M)
+{
+    push_pairs_to(a.worklist, a.wl_count, a.wl_capacity, a.wl_hist, a.status, a.n_paths, fw, rc, lane,
+                  path_global, slot, M);
 }
 
 // uint16 entry i of a 4-byte aligned LDS array, fetched with a 32-bit load.
@@ -514,11 +577,6 @@ __device__ __forceinline__ bool tail_equals(const uint16_t *__restrict__ bp, int
     return eq;
 }
 
-// Wave votes as 64-bit lane masks (SGPR pairs): most of the per-(wave, path)
-// bookkeeping below is scalar mask arithmetic, not per-lane code.
-using lanemask = unsigned long long;
-#define WAVE_MASK(pred) (__builtin_amdgcn_ballot_w64(pred))
-#define WAVE_ANY(pred) (__builtin_amdgcn_ballot_w64(pred) != 0ull)
 
 // Per-(wave, tile path) counters: lane p of `packed` holds good | bad << 16 for
 // tile path p; flushed into the 32-bit lanes before 16 bits can overflow.
@@ -947,7 +1005,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 6) void k_scan(ScanArgs a)
     // (Headers through scalar loads were measured 7 % slower: s_load shares the
     // lgkm counter with the LDS reads.)
     const int item_stride = SCAN_WAVES * a.n_chunks;
-    for (int it0 = chunk + wave * a.n_chunks; it0 < a.items.n_items; it0 += WAVE * item_stride) {
+    for (int it0 = a.item_lo + chunk + wave * a.n_chunks; it0 < a.items.n_items; it0 += WAVE * item_stride) {
         const int my_it = it0 + lane * item_stride;
         const bool mine = my_it < a.items.n_items;
         const uint4 hdr = mine ? a.items.hdr[my_it] : make_uint4(0u, 0u, NO_COMMON_NODE, 0u);
@@ -1008,6 +1066,844 @@ __global__ __launch_bounds__(SCAN_THREADS, 6) void k_scan(ScanArgs a)
     // per counter per workgroup
     wc.flush();
     const uint32_t cnt_good = wc.good, cnt_bad = wc.bad;
+    __syncthreads();
+    uint32_t *red = reinterpret_cast<uint32_t *>(lds);
+    if (tid < 2 * MAX_TILE) red[tid] = 0;
+    __syncthreads();
+    if (lane < tv.tile_paths) {
+        if (cnt_bad) atomicAdd(&red[lane], cnt_bad);
+        if (cnt_good) atomicAdd(&red[MAX_TILE + lane], cnt_good);
+    }
+    __syncthreads();
+    if (tid < tv.tile_paths) {
+        uint32_t d = red[tid], g = red[MAX_TILE + tid];
+        if (d) atomicAdd(&a.counts[tv.path0 + tid], d);
+        if (g) atomicAdd(&a.counts[a.n_paths + tv.path0 + tid], g);
+    }
+}
+
+// --------------------------------------------------------------------------
+// k_scan2: the same decisions as k_scan, with the subpath test answered for ALL
+// paths of the tile at once.
+//
+// k_scan walks, per (item, tile path), the occurrence chain of the alignment's
+// first node and compares windows: ~31 VALU + 23 SALU per (item, path), and it
+// is bound by instruction issue.  Here a workgroup is
+// (tile of T <= 8 paths) x (ONE alignment length M) x (chunk of the items of
+// that length).  Its prologue enters every M-step window of the tile's paths,
+// both strands, into an open-addressing table in LDS:
+//     slot -> { fingerprint | representative (path, strand, position) },
+//     mask[slot] = the tile paths that contain exactly this window
+// (identical windows of different paths share one entry: the insert compares
+// the steps themselves, so an entry stands for one window CONTENT).  An
+// alignment of M steps is a subpath of tile path p (either strand)  <=>  its
+// own step sequence is in the table with bit p set.  The alignment's hash is
+// path independent and precomputed by `create`; per item a lane does one
+// probe sequence, one exact comparison against the representative window,
+// and has the answer for all T paths.  The filter (src/eval.cpp:81-91) stays
+// the AND of per-node path masks; `m > n` is a constant mask per workgroup;
+// the start-overhang triage runs, as in k_scan, only for lanes whose
+// alignment contains the tile's first step.  Counters are kept per lane as
+// packed bytes (one byte per tile path) and reduced once per 255 items.
+// About 9 VALU per (item, path) at T = 8 instead of 31.
+//
+// The table holds H_CAP distinct windows.  Paths are entered one after the
+// other; similar paths -- prefixes of one walk, siblings of a search -- share
+// their windows and all fit.  If a path overflows the table, the table is
+// rebuilt without it and the workgroup makes a further pass over its items
+// for the remaining paths of the tile (exact for any input: one path alone
+// always fits).
+// --------------------------------------------------------------------------
+constexpr int H_LOG_S = 13;
+constexpr int H_SLOTS = 1 << H_LOG_S;
+constexpr uint32_t H_EMPTY = 0xFFFFFFFFu;
+constexpr int H_CAP = H_SLOTS / 2;        // distinct windows per table: load <= 1/2 (one path: < 2000)
+constexpr int TILE2_MAX = 8;              // one mask byte per slot
+constexpr int MAX_SEGS = 64;              // length segments per launch (one lane each)
+constexpr uint32_t H_FP_SHIFT = 14;       // entry: fp[31:14] | index of the window's first step in the staged steps [13:0]
+constexpr uint32_t NOT_A0 = 0x80000000u;  // node mask bit 31: node is NOT the tile's first node
+
+__host__ __device__ __forceinline__ uint32_t whash_init(int M)
+{
+    return 0x811C9DC5u ^ ((uint32_t)M * 0x9E3779B1u);
+}
+__host__ __device__ __forceinline__ uint32_t whash_step(uint32_t h, uint32_t code)
+{
+    return (h ^ code) * 0x01000193u;
+}
+__host__ __device__ __forceinline__ uint32_t whash_final(uint32_t h)
+{
+    h ^= h >> 16;
+    h *= 0x7FEB352Du;
+    h ^= h >> 15;
+    h *= 0x846CA68Bu;
+    h ^= h >> 16;
+    return h;
+}
+
+struct LenSeg {            // the items of one alignment length M
+    uint32_t item_lo, item_hi;
+    uint32_t m;
+    uint32_t n_chunks;     // (filled in per workgroup)
+    // item `it` of the segment: steps at items.steps[(step_base + (it - item_lo) * M) * 64],
+    // step pairs at pairs0[(p0_base + (it - item_lo) * ceil(M / 2)) * 64]
+    uint32_t step_base, p0_base;
+};
+
+struct Scan2Args {
+    Items items;
+    const uint32_t *item_hash;   // [n_items * 64] whash of every lane's alignment
+    // pairs0[.. * 64 + lane] = step 2j | step 2j+1 << 16 of the lane's alignment (ALL
+    // steps, two to a dword from step 0; 0xFFFF beyond the last): what a lane loads
+    // of its alignment, compared dword-wise against a window of the path
+    const uint32_t *pairs0;
+    const uint16_t *images;      // k_prep's path images (steps, reverse steps, length)
+    ImageLayout L;
+    const uint16_t *lids;        // [n_paths][L.nm] local node id per path position (0xFFFF none)
+    int n_paths, tile, n_tiles, filter;
+    int debug;                   // GFAL_DEBUG_SCAN2: 1 = prologue only (timing probe, wrong counters)
+    const LenSeg *segs;          // this launch's segments (<= MAX_SEGS), static per scorer
+    int n_segs;
+    // chunks of a segment of n items = clamp(min(n * chunk_mult, n * chunk_inv_min) >> 24, 1, 65535):
+    // the same integer arithmetic on the host (grid size) and in every workgroup
+    unsigned long long chunk_mult, chunk_inv_min;
+    uint32_t *counts;
+    unsigned long long *worklist;
+    unsigned long long *wl_count;
+    uint32_t wl_capacity;
+    uint32_t *wl_hist;
+    uint32_t *status;
+};
+
+__host__ __device__ __forceinline__ uint32_t seg_chunks(uint32_t n_items, unsigned long long mult,
+                                                        unsigned long long inv_min)
+{
+    const unsigned long long a = ((unsigned long long)n_items * mult) >> 24;
+    const unsigned long long b = ((unsigned long long)n_items * inv_min) >> 24;
+    const unsigned long long c = a < b ? a : b;
+    return (uint32_t)(c < 1ull ? 1ull : c > 65535ull ? 65535ull : c);
+}
+
+struct Tile2 {
+    const uint16_t *steps;       // [T][2][nm] forward | reverse-complement steps
+    const uint32_t *nodemask;    // [v2] bits 0..7: node on tile path p; bit 31: NOT_A0
+    const uint32_t *table;       // [H_SLOTS]
+    const uint8_t *maskb;        // [H_SLOTS]
+    int nm;
+    int tile_paths, path0;
+    int hdr_n;                   // lane p: length of tile path p
+    uint32_t hdr_a0;             // lane p: first step of tile path p
+    bool uniform_a0;             // all tile paths start with the same step
+    uint32_t sub_mask;           // tile paths of the current pass
+    uint32_t gt_mask;            // of those: shorter than M (every passing alignment is good)
+};
+
+// GFAL_STAMPS (diagnostic build only, scripts/stamp_probe.sh): where a wave's
+// cycles go inside scan2_item -- s_memtime stamps between the phases, summed per
+// wave and added to a debug buffer nothing else reads (status words 8..).
+#ifdef GFAL_STAMPS
+#define STAMP(t) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory")
+__device__ unsigned long long g_stamp_sum[8];
+__device__ unsigned long long g_stamp_wg[8];      // per wave: prologue, item loop, end-barrier wait, waves
+struct StampAcc {
+    unsigned long long v[8] = {};
+};
+#define STAMP_ACC StampAcc stamps;
+#else
+#define STAMP_ACC
+#endif
+
+// lane p: totals of tile path p; all lanes: byte p of packed_* counts this
+// lane's alignments for tile path p since the last flush (< 256 items)
+struct WaveCounts2 {
+    STAMP_ACC
+    uint32_t good = 0, bad = 0;
+    uint32_t g_lo = 0, g_hi = 0, b_lo = 0, b_hi = 0;
+    int items = 0;
+    __device__ __forceinline__ static uint32_t spread4(uint32_t m4)
+    {
+        // bit k of m4 -> bit 8k (k < 4): the partial products land on distinct bits
+        return (m4 * 0x00204081u) & 0x01010101u;
+    }
+    __device__ __forceinline__ void add(uint32_t good_mask, uint32_t bad_mask, int tile_paths)
+    {
+        g_lo += spread4(good_mask & 0xFu);
+        b_lo += spread4(bad_mask & 0xFu);
+        if (tile_paths > 4) {
+            g_hi += spread4((good_mask >> 4) & 0xFu);
+            b_hi += spread4((bad_mask >> 4) & 0xFu);
+        }
+        if (++items == 255) flush();
+    }
+    __device__ __forceinline__ static uint32_t wave_sum(uint32_t v)
+    {
+#pragma unroll
+        for (int o = 1; o < WAVE; o <<= 1) v += (uint32_t)__shfl_xor((int)v, o, WAVE);
+        return v;
+    }
+    __device__ __forceinline__ void flush()
+    {
+        const int lane = threadIdx.x & (WAVE - 1);
+        // two byte columns per reduction (sums stay below 64 * 255 < 2^16)
+        const uint32_t g02 = wave_sum(g_lo & 0x00FF00FFu), g13 = wave_sum((g_lo >> 8) & 0x00FF00FFu);
+        const uint32_t g46 = wave_sum(g_hi & 0x00FF00FFu), g57 = wave_sum((g_hi >> 8) & 0x00FF00FFu);
+        const uint32_t b02 = wave_sum(b_lo & 0x00FF00FFu), b13 = wave_sum((b_lo >> 8) & 0x00FF00FFu);
+        const uint32_t b46 = wave_sum(b_hi & 0x00FF00FFu), b57 = wave_sum((b_hi >> 8) & 0x00FF00FFu);
+        const uint32_t gsel = lane < 4 ? ((lane & 1) ? g13 : g02) : ((lane & 1) ? g57 : g46);
+        const uint32_t bsel = lane < 4 ? ((lane & 1) ? b13 : b02) : ((lane & 1) ? b57 : b46);
+        if (lane < TILE2_MAX) {
+            good += (lane & 2) ? (gsel >> 16) : (gsel & 0xFFFFu);
+            bad += (lane & 2) ? (bsel >> 16) : (bsel & 0xFFFFu);
+        }
+        g_lo = g_hi = b_lo = b_hi = 0;
+        items = 0;
+    }
+};
+
+// dedup scorers: a lane stands for w identical alignments
+struct WaveCounts2W {
+    STAMP_ACC
+    uint32_t good = 0, bad = 0;
+    uint32_t g[TILE2_MAX] = {}, b[TILE2_MAX] = {};
+    __device__ __forceinline__ void add(uint32_t good_mask, uint32_t bad_mask, uint32_t w)
+    {
+#pragma unroll
+        for (int p = 0; p < TILE2_MAX; ++p) {
+            g[p] += ((good_mask >> p) & 1u) ? w : 0u;
+            b[p] += ((bad_mask >> p) & 1u) ? w : 0u;
+        }
+    }
+    __device__ __forceinline__ void flush()
+    {
+        const int lane = threadIdx.x & (WAVE - 1);
+#pragma unroll
+        for (int p = 0; p < TILE2_MAX; ++p) {
+            const uint32_t gs = WaveCounts2::wave_sum(g[p]), bs = WaveCounts2::wave_sum(b[p]);
+            if (lane == p) {
+                good += gs;
+                bad += bs;
+            }
+            g[p] = b[p] = 0;
+        }
+    }
+};
+
+// A wave-uniform pointer, pinned to an SGPR pair: the per-lane offset is then
+// added by the load itself (global_load v, v_off, s[base]) instead of living as
+// a hoisted 64-bit VGPR pair per array (k_scan spills exactly those).
+// The result is typed as a GLOBAL pointer: after the asm the compiler no longer
+// knows where the pointer came from, and a generic pointer would be loaded with
+// flat_load (which counts on lgkmcnt too, so every LDS wait would also wait for
+// the item loads issued ahead).
+#define GLOBAL_AS __attribute__((address_space(1)))
+template <typename T>
+__device__ __forceinline__ const GLOBAL_AS T *sgpr_ptr(const T *p)
+{
+    asm volatile("" : "+s"(p));
+    return (const GLOBAL_AS T *)p;
+}
+
+// step t of the window (strand, pos) of a tile path, from the staged steps
+__device__ __forceinline__ uint32_t tile_step(const uint16_t *steps, int nm, uint32_t path_strand,
+                                              uint32_t pos)
+{
+    return steps[path_strand * (uint32_t)nm + pos];
+}
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+{
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) v += (uint32_t)__shfl_xor((int)v, o, WAVE);
+    return v;
+}
+
+// Prologue: enter the M-step windows of tile path p (both strands) into the table.
+__device__ __forceinline__ void insert_windows(uint16_t *steps, int nm, uint32_t *table,
+                                               uint32_t *maskw, uint32_t *used, int p, int n, int M,
+                                               int tid)
+{
+    const int n_win = n - M + 1;                 // windows per strand
+    uint32_t fresh = 0;                          // entries this thread created
+    for (int w = tid; w < 2 * n_win; w += SCAN_THREADS) {
+        const uint32_t strand = w >= n_win ? 1u : 0u;
+        const uint32_t pos = (uint32_t)(strand ? w - n_win : w);
+        const uint32_t idx = ((uint32_t)p * 2u + strand) * (uint32_t)nm + pos;
+        const uint16_t *win = steps + idx;
+        uint32_t h = whash_init(M);
+        bool real = true;
+        for (int t = 0; t < M; ++t) {
+            const uint32_t c = win[t];
+            real &= c < STEP_NOMATCH;            // a step that equals nothing: no alignment matches
+            h = whash_step(h, c);
+        }
+        if (!real) continue;
+        h = whash_final(h);
+        const uint32_t want = (h & ~((1u << H_FP_SHIFT) - 1u)) | idx;
+        uint32_t slot = h & (H_SLOTS - 1u);
+        const uint32_t stride = ((h >> H_LOG_S) & (H_SLOTS - 1u)) | 1u;
+        while (true) {
+            const uint32_t old = atomicCAS(&table[slot], H_EMPTY, want);
+            if (old == H_EMPTY) {
+                ++fresh;
+                break;
+            }
+            if (((old ^ h) >> H_FP_SHIFT) == 0u) {      // same fingerprint: the same window?
+                const uint16_t *rep = steps + (old & ((1u << H_FP_SHIFT) - 1u));
+                bool same = true;
+                for (int t = 0; t < M; ++t) same &= rep[t] == win[t];
+                if (same) break;
+            }
+            slot = (slot + stride) & (H_SLOTS - 1u);
+        }
+        atomicOr(&maskw[slot >> 2], (1u << p) << ((slot & 3u) * 8u));
+    }
+    // one add per wave (64 lanes on one LDS word serialise)
+    fresh = wave_sum_u32(fresh);
+    if ((tid & (WAVE - 1)) == 0 && fresh) {
+        if (atomicAdd(used, fresh) + fresh > (uint32_t)H_CAP) used[1] = 1u;     // overflow: see k_scan2
+    }
+}
+
+// One item against the tile (all lanes: one alignment each, M steps).
+// What a lane holds of its alignment of one item (loaded one item ahead):
+// P0 = ceil(M / 2) step pairs (from step 0), its hash, its weight.
+template <int P0>
+struct ItemRegs {
+    uint32_t p0[P0 > 0 ? P0 : 1];
+    uint32_t h, w;
+    uint32_t it;             // (uniform) the item
+};
+
+template <int P0, int MC, bool W, typename Counts>
+__device__ __forceinline__ void scan2_item(const Scan2Args &a, const Tile2 &tv, const LenSeg &sg,
+                                           const ItemRegs<P0> &r, int M_rt, int lane, Counts &wc)
+{
+    const int M = MC ? MC : M_rt;
+#ifdef GFAL_STAMPS
+    unsigned long long st0, st1, st2, st3, st4;
+    STAMP(st0);
+#endif
+    const uint32_t h = r.h, w = r.w;
+    const uint8_t *tb = reinterpret_cast<const uint8_t *>(tv.table);
+    const uint32_t *step32 = reinterpret_cast<const uint32_t *>(tv.steps);
+    // first probe and its path mask go out together with the node-mask reads: one
+    // LDS round trip for all of them
+    const uint32_t stride4 = (((h >> H_LOG_S) & (H_SLOTS - 1u)) | 1u) << 2;
+    uint32_t slot4 = (h & (H_SLOTS - 1u)) << 2;
+    uint32_t e = *reinterpret_cast<const uint32_t *>(tb + slot4);
+    uint32_t mword = *reinterpret_cast<const uint32_t *>(tb + 4u * H_SLOTS + (slot4 >> 2 & ~3u));
+
+    uint32_t p0[P0];
+#pragma unroll
+    for (int k = 0; k < P0; ++k) p0[k] = r.p0[k];
+    const bool valid = (p0[0] & 0xFFFFu) != STEP_INVALID;
+    if (!valid) {           // keep table indices in range on padding lanes
+#pragma unroll
+        for (int k = 0; k < P0; ++k) p0[k] = 0;
+    }
+    // bits 0..7: every node of this alignment is on tile path p (the filter of
+    // src/eval.cpp:81-91); bit 31 survives iff NO step is on the tile's first node
+    uint32_t pm = 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 0; k < P0; ++k) {
+        pm &= tv.nodemask[(p0[k] & 0xFFFFu) >> 1];
+        if (k + 1 < P0 || !(M & 1)) pm &= tv.nodemask[p0[k] >> 17];
+    }
+    uint32_t pass = a.filter ? pm : 0xFFu;
+    pass = valid ? (pass & tv.sub_mask) : 0u;
+    const bool has_a0 = !tv.uniform_a0 || (pm & NOT_A0) == 0u;
+    const uint32_t gt = pass & tv.gt_mask;          // src/alignments.cpp:500: m > n -> good
+    const uint32_t todo = pass & ~tv.gt_mask;
+#ifdef GFAL_STAMPS
+    asm volatile("" ::"v"(todo), "v"(gt));
+    STAMP(st1);
+#endif
+
+    // ---- window lookup: which of the tile's paths contain this step sequence ----
+    uint32_t fmask = 0;
+    {
+        bool searching = todo != 0u;
+        while (true) {
+            // probe on until an empty slot or an entry with this fingerprint
+            while (true) {
+                const bool stop = !searching || e == H_EMPTY || ((e ^ h) >> H_FP_SHIFT) == 0u;
+                if (!WAVE_ANY(!stop)) break;
+                slot4 = stop ? slot4 : ((slot4 + stride4) & (4u * H_SLOTS - 1u));
+                const uint32_t e2 = *reinterpret_cast<const uint32_t *>(tb + slot4);
+                const uint32_t m2 = *reinterpret_cast<const uint32_t *>(tb + 4u * H_SLOTS + (slot4 >> 2 & ~3u));
+                e = stop ? e : e2;
+                mword = stop ? mword : m2;
+#ifdef GFAL_STAMPS
+                wc.stamps.v[5] += 1;      // extra probe rounds
+#endif
+            }
+            const bool cand = searching && e != H_EMPTY;
+            if (!WAVE_ANY(cand)) break;
+            // exact comparison with the entry's window: P0 dwords of the path's steps
+            // from the window's first step on (lanes without a candidate read the
+            // start of the steps and are masked off)
+            const uint32_t idx = cand ? (e & ((1u << H_FP_SHIFT) - 1u)) : 0u;
+            const uint32_t *wd = step32 + (idx >> 1);
+            const uint32_t sh = idx << 4;               // alignbit uses bits 4:0: 0 or 16
+            uint32_t d[P0 + 1];
+#pragma unroll
+            for (int k = 0; k <= P0; ++k) d[k] = wd[k];
+            bool ok = cand;
+#pragma unroll
+            for (int k = 0; k < P0; ++k) {
+                const uint32_t got = __builtin_amdgcn_alignbit(d[k + 1], d[k], sh);
+                if (k + 1 < P0 || !(M & 1)) ok &= got == p0[k];
+                else ok &= ((got ^ p0[k]) & 0xFFFFu) == 0u;       // M odd: one step in the last pair
+            }
+            if (ok) fmask = (mword >> ((slot4 << 1) & 24u)) & 0xFFu;
+            // a fingerprint collision (cand && !ok) keeps probing; everything else is settled
+            searching = cand && !ok;
+            if (!WAVE_ANY(searching)) break;
+            slot4 = searching ? ((slot4 + stride4) & (4u * H_SLOTS - 1u)) : slot4;
+            e = *reinterpret_cast<const uint32_t *>(tb + slot4);
+            mword = *reinterpret_cast<const uint32_t *>(tb + 4u * H_SLOTS + (slot4 >> 2 & ~3u));
+        }
+    }
+    fmask &= todo;
+    const uint32_t good_mask = gt | fmask;
+    const uint32_t open = todo & ~fmask;
+    uint32_t bad_mask = open;
+#ifdef GFAL_STAMPS
+    asm volatile("" ::"v"(open));
+    STAMP(st2);
+#endif
+
+    // ---- start-overhang triage (as in k_scan): B is not a subpath and m <= n ----
+    // The traceback stays free only if a proper suffix of B (or of rc(B)) equals a
+    // prefix of the path; survivors of this exact test go to the DP kernels.  Few
+    // items have such lanes (the alignment must touch the tile's first node), but
+    // a wave that gets here holds up its whole workgroup: everything comes from
+    // registers and LDS, and the item makes ONE returning atomic for all its pairs.
+    if (WAVE_ANY(open != 0u && has_a0)) {
+#ifdef GFAL_STAMPS
+        wc.stamps.v[6] += 1;                         // items that enter the triage
+        wc.stamps.v[7] += __popcll(WAVE_MASK(open != 0u && has_a0));    // lanes that ask for it
+#endif
+        uint32_t cfw = 0, crc = 0;                   // bit p: candidate on tile path p
+        // step t of B, t a compile-time constant after unrolling
+        auto stepB = [&](int t) -> uint32_t { return (p0[t >> 1] >> ((t & 1) * 16)) & 0xFFFFu; };
+        for (int p = 0; p < tv.tile_paths; ++p) {
+            const bool mine = ((open >> p) & 1u) != 0u && has_a0;
+            if (!WAVE_ANY(mine)) continue;
+            const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)tv.hdr_a0, p);
+            const uint32_t *pstep32 = step32 + (uint32_t)p * (uint32_t)tv.nm;   // 2 * nm u16 per path
+            bool cand_fw = false, cand_rc = false;
+            if constexpr (MC != 0) {
+                // the path's first M steps (the same for every lane: broadcast reads)
+                uint32_t pre[P0];
+#pragma unroll
+                for (int k = 0; k < P0; ++k) pre[k] = pstep32[k];
+                auto stepA = [&](int k) -> uint32_t { return (pre[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu; };
+#pragma unroll
+                for (int t = 0; t < MC; ++t) {
+                    const uint32_t bt = stepB(t);
+                    if (t >= 1) {                     // B[t..M) == path[0..M-t) ?
+                        bool eq = mine && bt == a0;
+#pragma unroll
+                        for (int k = 1; k < MC - t; ++k) eq &= stepB(t + k) == stepA(k);
+                        cand_fw |= eq;
+                    }
+                    if (t < MC - 1) {                 // rc(B)[M-1-t..M) == path[0..t+1) ?
+                        bool eq = mine && (bt ^ 1u) == a0;
+#pragma unroll
+                        for (int k = 1; k <= t; ++k) eq &= (stepB(t - k) ^ 1u) == stepA(k);
+                        cand_rc |= eq;
+                    }
+                }
+            } else {
+                const uint16_t *bp = a.items.steps +
+                                     ((size_t)sg.step_base + (size_t)(r.it - sg.item_lo) * (uint32_t)M) * WAVE + lane;
+                for (int t = 0; t < M; ++t) {      // (rare lengths: steps re-read from the item)
+                    const uint32_t bt = bp[t * WAVE];
+                    const bool live_fw = mine && t >= 1 && bt == a0;
+                    if (WAVE_ANY(live_fw)) cand_fw |= tail_equals(bp, t, 1, M - t, 0u, pstep32, live_fw);
+                    const bool live_rc = mine && t < M - 1 && (bt ^ 1u) == a0;
+                    if (WAVE_ANY(live_rc)) cand_rc |= tail_equals(bp, t, -1, t + 1, 1u, pstep32, live_rc);
+                }
+            }
+            cfw |= cand_fw ? (1u << p) : 0u;
+            crc |= cand_rc ? (1u << p) : 0u;
+        }
+        const uint32_t cany = cfw | crc;
+        bad_mask &= ~cany;
+        push_item_pairs(a.worklist, a.wl_count, a.wl_capacity, a.wl_hist, a.status, a.n_paths, cfw, crc,
+                        lane, (uint32_t)tv.path0, tv.tile_paths, r.it * WAVE + (uint32_t)lane, M);
+    }
+#ifdef GFAL_STAMPS
+    asm volatile("" ::"v"(bad_mask));
+    STAMP(st3);
+#endif
+    if constexpr (W) wc.add(good_mask, bad_mask, w);
+    else wc.add(good_mask, bad_mask, tv.tile_paths);
+#ifdef GFAL_STAMPS
+    STAMP(st4);
+    wc.stamps.v[0] += st1 - st0;     // item regs ready + node masks + first probe
+    wc.stamps.v[1] += st2 - st1;     // window lookup
+    wc.stamps.v[2] += st3 - st2;     // triage
+    wc.stamps.v[3] += st4 - st3;     // counting
+    wc.stamps.v[4] += 1;             // items
+#endif
+}
+
+// The same for alignments too long for registers (M > 2 * MAX_REG_K + 1): steps are
+// re-read from the item where needed.
+template <bool W, typename Counts>
+__device__ __forceinline__ void scan2_item_long(const Scan2Args &a, const Tile2 &tv,
+                                                const uint16_t *__restrict__ bp, uint32_t h, int M,
+                                                int lane, uint32_t slot_id, Counts &wc, uint32_t w)
+{
+    const uint32_t first_step = bp[0];
+    const bool valid = first_step != STEP_INVALID;
+    uint32_t pm = 0xFFFFFFFFu;
+    for (int t = 0; t < M; ++t) {
+        const uint32_t bt = valid ? (uint32_t)bp[t * WAVE] : 0u;
+        pm &= tv.nodemask[bt >> 1];
+    }
+    uint32_t pass = a.filter ? pm : 0xFFu;
+    pass = valid ? (pass & tv.sub_mask) : 0u;
+    const bool has_a0 = !tv.uniform_a0 || (pm & NOT_A0) == 0u;
+    const uint32_t gt = pass & tv.gt_mask;
+    const uint32_t todo = pass & ~tv.gt_mask;
+    uint32_t fmask = 0;
+    {
+        const uint32_t stride4 = (((h >> H_LOG_S) & (H_SLOTS - 1u)) | 1u) << 2;
+        uint32_t slot4 = (h & (H_SLOTS - 1u)) << 2;
+        const uint8_t *tb = reinterpret_cast<const uint8_t *>(tv.table);
+        bool searching = todo != 0u;
+        while (WAVE_ANY(searching)) {
+            uint32_t e;
+            while (true) {
+                e = *reinterpret_cast<const uint32_t *>(tb + slot4);
+                const bool stop = !searching || e == H_EMPTY || ((e ^ h) >> H_FP_SHIFT) == 0u;
+                if (!WAVE_ANY(!stop)) break;
+                slot4 = stop ? slot4 : ((slot4 + stride4) & (4u * H_SLOTS - 1u));
+            }
+            const bool cand = searching && e != H_EMPTY;
+            const uint16_t *win = tv.steps + (cand ? (e & ((1u << H_FP_SHIFT) - 1u)) : 0u);
+            bool ok = cand;
+            for (int t = 0; t < M; ++t) ok &= (uint32_t)win[cand ? t : 0] == (uint32_t)bp[t * WAVE];
+            if (ok) fmask = tb[4u * H_SLOTS + (slot4 >> 2)];
+            searching = cand && !ok;
+            slot4 = searching ? ((slot4 + stride4) & (4u * H_SLOTS - 1u)) : slot4;
+        }
+    }
+    fmask &= todo;
+    const uint32_t good_mask = gt | fmask;
+    const uint32_t open = todo & ~fmask;
+    uint32_t bad_mask = open;
+    if (WAVE_ANY(open != 0u && has_a0)) {
+        const uint32_t *step32 = reinterpret_cast<const uint32_t *>(tv.steps);
+        for (int p = 0; p < tv.tile_paths; ++p) {
+            const bool mine = ((open >> p) & 1u) != 0u && has_a0;
+            if (!WAVE_ANY(mine)) continue;
+            const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)tv.hdr_a0, p);
+            const uint32_t *pstep32 = step32 + (uint32_t)p * (uint32_t)tv.nm;
+            bool cand_fw = false, cand_rc = false;
+            for (int t = 0; t < M; ++t) {
+                const uint32_t bt = bp[t * WAVE];
+                const bool live_fw = mine && t >= 1 && bt == a0;
+                if (WAVE_ANY(live_fw)) cand_fw |= tail_equals(bp, t, 1, M - t, 0u, pstep32, live_fw);
+                const bool live_rc = mine && t < M - 1 && (bt ^ 1u) == a0;
+                if (WAVE_ANY(live_rc)) cand_rc |= tail_equals(bp, t, -1, t + 1, 1u, pstep32, live_rc);
+            }
+            if (cand_fw || cand_rc) bad_mask &= ~(1u << p);
+            push_pairs_to(a.worklist, a.wl_count, a.wl_capacity, a.wl_hist, a.status, a.n_paths,
+                          cand_fw, cand_rc, lane, (uint32_t)(tv.path0 + p), slot_id, M);
+        }
+    }
+    if constexpr (W) wc.add(good_mask, bad_mask, w);
+    else wc.add(good_mask, bad_mask, tv.tile_paths);
+}
+
+// The wave's items of one segment chunk, 64 at a time (as in k_scan: one ballot
+// drops the items none of whose lanes can pass the filter).  P0 = ceil(M / 2)
+// pair dwords per lane in registers, or -1: long alignments.
+template <int P0, int MC, bool W, typename Counts>
+__device__ __forceinline__ void scan2_items(const Scan2Args &a, const Tile2 &tv, const LenSeg &sg,
+                                            int chunk, int wave, int lane, Counts &wc)
+{
+    const int n_chunks = (int)sg.n_chunks;
+    const int item_stride = SCAN_WAVES * n_chunks;
+    const int M = (int)sg.m;
+    const uint32_t ulane = (uint32_t)lane;
+    for (int it0 = (int)sg.item_lo + chunk + wave * n_chunks; it0 < (int)sg.item_hi;
+         it0 += WAVE * item_stride) {
+        const int my_it = it0 + lane * item_stride;
+        const bool mine = my_it < (int)sg.item_hi;
+        bool keep = mine;
+        if (a.filter && mine) {
+            const uint32_t common = a.items.common[my_it];
+            if (common != NO_COMMON_NODE) {
+                const uint32_t m1 = tv.nodemask[common & 0x7FFFu], m2 = tv.nodemask[common >> 16];
+                keep = (((common & COMMON_EITHER) ? (m1 | m2) : (m1 & m2)) & tv.sub_mask) != 0u;
+            }
+        }
+        lanemask todo = WAVE_MASK(keep);
+        if (todo == 0) continue;
+        if constexpr (P0 > 0 && P0 <= 6) {
+            // The loads of an item are issued while the previous one is decided.  Two
+            // register sets, used in turn (no copies), and the load ahead is
+            // UNCONDITIONAL (past the last item it re-reads that item): at every use
+            // exactly one younger set of loads is in flight, so the compiler can wait
+            // with a counted vmcnt instead of draining the loads issued ahead.
+            auto load_item = [&](int src_in, ItemRegs<P0> &r) {
+                const int src = __builtin_amdgcn_readfirstlane(src_in);     // (uniform: from a ballot)
+                const uint32_t it = (uint32_t)(it0 + src * item_stride);
+                r.it = it;
+                r.h = sgpr_ptr(a.item_hash + (size_t)it * WAVE)[ulane];
+                r.w = W ? sgpr_ptr(a.items.weight + (size_t)it * WAVE)[ulane] : 1u;
+                const GLOBAL_AS uint32_t *pp =
+                    sgpr_ptr(a.pairs0 + ((size_t)sg.p0_base + (size_t)(it - sg.item_lo) * P0) * WAVE) + ulane;
+#pragma unroll
+                for (int k = 0; k < P0; ++k) r.p0[k] = pp[k * WAVE];
+            };
+            ItemRegs<P0> ra, rb;
+            load_item(__builtin_ctzll(todo), ra);
+            while (true) {
+                lanemask rest = todo & (todo - 1);
+                load_item(__builtin_ctzll(rest ? rest : todo), rb);
+                scan2_item<P0, MC, W>(a, tv, sg, ra, M, lane, wc);
+                if (rest == 0) break;
+                todo = rest;
+                rest = todo & (todo - 1);
+                load_item(__builtin_ctzll(rest ? rest : todo), ra);
+                scan2_item<P0, MC, W>(a, tv, sg, rb, M, lane, wc);
+                if (rest == 0) break;
+                todo = rest;
+            }
+        } else {      // long alignments are rare: no second register set for them
+            for (; todo != 0; todo &= todo - 1) {
+                const int src = __builtin_amdgcn_readfirstlane(__builtin_ctzll(todo));
+                const uint32_t it = (uint32_t)(it0 + src * item_stride);
+                const uint32_t h = a.item_hash[(size_t)it * WAVE + ulane];
+                const uint32_t w = W ? a.items.weight[(size_t)it * WAVE + ulane] : 1u;
+                if constexpr (P0 < 0) {
+                    const uint16_t *bp = a.items.steps +
+                                         ((size_t)sg.step_base + (size_t)(it - sg.item_lo) * (uint32_t)M) * WAVE + ulane;
+                    scan2_item_long<W>(a, tv, bp, h, M, lane, it * WAVE + ulane, wc, w);
+                } else {
+                    ItemRegs<P0> r;
+                    r.it = it;
+                    r.h = h;
+                    r.w = w;
+                    const uint32_t *pp = a.pairs0 + ((size_t)sg.p0_base + (size_t)(it - sg.item_lo) * P0) * WAVE + ulane;
+#pragma unroll
+                    for (int k = 0; k < P0; ++k) r.p0[k] = pp[k * WAVE];
+                    scan2_item<P0, MC, W>(a, tv, sg, r, M, lane, wc);
+                }
+            }
+        }
+    }
+#ifdef GFAL_STAMPS
+    if (lane == 0)
+        for (int k = 0; k < 8; ++k)
+            if (wc.stamps.v[k]) atomicAdd(&g_stamp_sum[k], wc.stamps.v[k]);
+#endif
+}
+
+template <bool W>
+__global__ __launch_bounds__(SCAN_THREADS, 6) void k_scan2(Scan2Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & (WAVE - 1);
+    // wave-uniform by construction; saying so keeps item indices and base
+    // pointers in SGPRs
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile_id = blockIdx.x % a.n_tiles;
+    // (segment, chunk) <- the workgroup's row: lane k sizes segment k, a prefix sum
+    // over the lanes finds the row's segment
+    LenSeg sg;
+    int chunk;
+    {
+        const int y = blockIdx.x / a.n_tiles;
+        LenSeg mine{0u, 0u, 0u, 0u, 0u, 0u};
+        if (lane < a.n_segs) mine = a.segs[lane];
+        const uint32_t c = lane < a.n_segs
+                               ? seg_chunks(mine.item_hi - mine.item_lo, a.chunk_mult, a.chunk_inv_min)
+                               : 0u;
+        uint32_t incl = c;
+#pragma unroll
+        for (int o = 1; o < WAVE; o <<= 1) {
+            const uint32_t v = (uint32_t)__shfl_up((int)incl, o, WAVE);
+            if (lane >= o) incl += v;
+        }
+        const lanemask beyond = WAVE_MASK(incl > (uint32_t)y);    // first set lane: my segment
+        const int seg = beyond ? __builtin_ctzll(beyond) : 0;
+        sg.item_lo = (uint32_t)__builtin_amdgcn_readlane((int)mine.item_lo, seg);
+        sg.item_hi = (uint32_t)__builtin_amdgcn_readlane((int)mine.item_hi, seg);
+        sg.m = (uint32_t)__builtin_amdgcn_readlane((int)mine.m, seg);
+        sg.n_chunks = (uint32_t)__builtin_amdgcn_readlane((int)c, seg);
+        sg.step_base = (uint32_t)__builtin_amdgcn_readlane((int)mine.step_base, seg);
+        sg.p0_base = (uint32_t)__builtin_amdgcn_readlane((int)mine.p0_base, seg);
+        chunk = y - (int)__builtin_amdgcn_readlane((int)(incl - c), seg);
+    }
+    const int M = (int)sg.m;
+
+#ifdef GFAL_STAMPS
+    unsigned long long wg0, wg1, wg2, wg3, wg_items = 0;
+    STAMP(wg0);
+#endif
+    Tile2 tv;
+    tv.path0 = tile_id * a.tile;
+    tv.tile_paths = min(a.tile, a.n_paths - tv.path0);
+    tv.nm = a.L.nm;
+    const int nm = a.L.nm;
+    uint16_t *steps = lds;                                          // [tile][2][nm]
+    uint32_t *nodemask = reinterpret_cast<uint32_t *>(lds + (size_t)a.tile * 2 * nm);
+    uint32_t *table = nodemask + a.L.v2;
+    uint32_t *maskw = table + H_SLOTS;                              // H_SLOTS bytes
+    uint32_t *misc = maskw + H_SLOTS / 4;                           // [0]: entries in the table
+    tv.steps = steps;
+    tv.nodemask = nodemask;
+    tv.table = table;
+    tv.maskb = reinterpret_cast<const uint8_t *>(maskw);
+
+    // stage the steps of the tile's paths (forward | reverse complement: contiguous
+    // in the image, 4-byte aligned) and start the node masks
+    for (int p = 0; p < tv.tile_paths; ++p) {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(
+            a.images + (size_t)(tv.path0 + p) * a.L.total + a.L.step_at());
+        uint32_t *dst = reinterpret_cast<uint32_t *>(steps + (size_t)p * 2 * nm);
+        for (int i = tid; i < nm; i += SCAN_THREADS) dst[i] = src[i];
+    }
+    for (int v = tid; v < a.L.v2; v += SCAN_THREADS) nodemask[v] = NOT_A0;
+    tv.hdr_n = 0;
+    tv.hdr_a0 = STEP_NOMATCH;
+    if (lane < tv.tile_paths) {
+        const uint16_t *img = a.images + (size_t)(tv.path0 + lane) * a.L.total;
+        tv.hdr_n = img[a.L.len_at()];
+        tv.hdr_a0 = img[a.L.step_at()];
+    }
+    const uint32_t tile_a0 = (uint32_t)__builtin_amdgcn_readlane((int)tv.hdr_a0, 0);
+    tv.uniform_a0 = WAVE_MASK(lane < tv.tile_paths && tv.hdr_a0 != tile_a0) == 0ull;
+    __syncthreads();
+    // which tile paths carry each node (the filter of src/eval.cpp:81-91 as a bit
+    // test); the node of the tile's first step loses NOT_A0
+    for (int p = 0; p < tv.tile_paths; ++p) {
+        const int n = __builtin_amdgcn_readlane(tv.hdr_n, p);
+        const uint16_t *lid = a.lids + (size_t)(tv.path0 + p) * nm;
+        for (int i = tid; i < n; i += SCAN_THREADS) {
+            const uint32_t v = lid[i];
+            if (v != 0xFFFFu) atomicOr(&nodemask[v], 1u << p);
+        }
+    }
+    if (tid == 0 && tile_a0 < STEP_NOMATCH) atomicAnd(&nodemask[tile_a0 >> 1], ~NOT_A0);
+    __syncthreads();
+
+    uint32_t cnt_good = 0, cnt_bad = 0;      // lane p: totals of tile path p over all passes
+    // passes over the tile's paths: as many paths per pass as fit the table
+    int t0 = 0;
+    while (t0 < tv.tile_paths) {
+        int t1 = t0, limit = tv.tile_paths;
+        uint32_t gt_mask = 0;
+        while (true) {                         // second round only after an overflow
+            __syncthreads();
+            for (int i = tid; i < H_SLOTS; i += SCAN_THREADS) table[i] = H_EMPTY;
+            for (int i = tid; i < H_SLOTS / 4; i += SCAN_THREADS) maskw[i] = 0;
+            if (tid < 2) misc[tid] = 0;        // [0] entries, [1] overflow flag
+            __syncthreads();
+            t1 = t0;
+            gt_mask = 0;
+            bool overflow = false;
+            while (t1 < limit) {
+                const int n = __builtin_amdgcn_readlane(tv.hdr_n, t1);
+                if (n < M) {
+                    gt_mask |= 1u << t1;      // no windows: every passing alignment is good
+                } else {
+                    insert_windows(steps, nm, table, maskw, misc, t1, n, M, tid);
+                    __syncthreads();
+                    overflow = misc[1] != 0u;
+                    if (overflow) break;
+                }
+                ++t1;
+            }
+            if (!overflow) break;
+            // path t1 did not fit beside [t0, t1): rebuild the table without it (the
+            // masks already carry its bit); it starts the next pass.  One path alone
+            // always fits (< 2000 windows), so t1 > t0 here.
+            limit = t1;
+        }
+        if (t1 == t0) t1 = t0 + 1;            // (unreachable; never loop forever)
+        tv.sub_mask = ((t1 >= 32 ? 0u : (1u << t1)) - 1u) & ~((1u << t0) - 1u);
+        tv.gt_mask = gt_mask;
+
+#ifdef GFAL_STAMPS
+        STAMP(wg1);
+#endif
+        LenSeg sgl = sg;
+        if (a.debug == 1) sgl.item_hi = sgl.item_lo;      // timing probe: no items
+        if (a.debug >= 2 && M != a.debug) sgl.item_hi = sgl.item_lo;   // timing probe: one length only
+#define GFAL_RUN(KK, MM)                                                        \
+    do {                                                                        \
+        if constexpr (W) {                                                      \
+            WaveCounts2W wc;                                                    \
+            scan2_items<KK, MM, true>(a, tv, sgl, chunk, wave, lane, wc);       \
+            wc.flush();                                                         \
+            cnt_good += wc.good;                                                \
+            cnt_bad += wc.bad;                                                  \
+        } else {                                                                \
+            WaveCounts2 wc;                                                     \
+            scan2_items<KK, MM, false>(a, tv, sgl, chunk, wave, lane, wc);      \
+            wc.flush();                                                         \
+            cnt_good += wc.good;                                                \
+            cnt_bad += wc.bad;                                                  \
+        }                                                                       \
+    } while (0)
+#ifdef GFAL_ONLY_M      // codegen experiment: a kernel that knows one length only
+        if (M == GFAL_ONLY_M) GFAL_RUN((GFAL_ONLY_M + 1) / 2, GFAL_ONLY_M);
+#else
+        if (M > 2 * MAX_REG_K + 1) {
+            GFAL_RUN(-1, 0);
+        } else {
+            switch (M) {
+#define GFAL_CASE(MM) case MM: GFAL_RUN((MM + 1) / 2, MM); break;
+                GFAL_CASE(1) GFAL_CASE(2) GFAL_CASE(3) GFAL_CASE(4)
+                GFAL_CASE(5) GFAL_CASE(6) GFAL_CASE(7) GFAL_CASE(8)
+                GFAL_CASE(9) GFAL_CASE(10) GFAL_CASE(11) GFAL_CASE(12)
+#undef GFAL_CASE
+            default: {
+                switch ((M + 1) / 2) {           // pair dwords; M itself at run time
+#define GFAL_CASE(PP) case PP: GFAL_RUN(PP, 0); break;
+                    GFAL_CASE(7) GFAL_CASE(8) GFAL_CASE(9) GFAL_CASE(10) GFAL_CASE(11)
+                    GFAL_CASE(12) GFAL_CASE(13) GFAL_CASE(14) GFAL_CASE(15) GFAL_CASE(16)
+                    GFAL_CASE(17)
+#undef GFAL_CASE
+                }
+            }
+            }
+        }
+#endif
+#undef GFAL_RUN
+#ifdef GFAL_STAMPS
+        STAMP(wg2);
+        wg_items += wg2 - wg1;
+#endif
+        t0 = t1;
+        __syncthreads();                       // the table is rebuilt for the next pass
+#ifdef GFAL_STAMPS
+        STAMP(wg3);
+        if (lane == 0) {
+            atomicAdd(&g_stamp_wg[2], wg3 - wg2);      // waiting for the slowest wave
+            atomicAdd(&g_stamp_wg[4], 1ull);           // passes x waves
+        }
+#endif
+    }
+#ifdef GFAL_STAMPS
+    if (lane == 0) {
+        atomicAdd(&g_stamp_wg[1], wg_items);
+        atomicAdd(&g_stamp_wg[0], wg3 - wg0 - wg_items);     // everything that is not the item loop
+        atomicAdd(&g_stamp_wg[3], 1ull);
+    }
+#endif
+
+    // workgroup reduction through LDS (the steps are dead now), then one atomic
+    // per counter per workgroup
     __syncthreads();
     uint32_t *red = reinterpret_cast<uint32_t *>(lds);
     if (tid < 2 * MAX_TILE) red[tid] = 0;
@@ -1840,6 +2736,17 @@ struct gfal_scorer {
     uint32_t *d_item_common = nullptr;   // Items::common
     uint4 *d_item_hdr = nullptr;         // Items::hdr
     uint32_t *d_item_weight = nullptr;   // Items::weight (dedup scorers)
+    uint32_t *d_item_hash = nullptr;     // [n_items * 64] whash of every lane (k_scan2)
+    uint32_t *d_item_pairs0 = nullptr;   // Scan2Args::pairs0
+    // k_scan2 takes the items of the well-populated alignment lengths: they come
+    // first in the item order, one contiguous segment per length; the items of
+    // the rare lengths follow and are scanned by k_scan
+    std::vector<LenSeg> segs;            // every length, in item order
+    LenSeg *d_segs = nullptr;            // the same on the device
+    int n_hash_items = 0, n_hash_segs = 0;   // the k_scan2 prefix of items / segs
+    int scan_mode = 0;                   // GFAL_SCAN: 0 auto, 1 k_scan only, 2 k_scan2 only
+    uint16_t *d_lids = nullptr;          // [n_paths][nm] node ids along the paths (per call)
+    size_t lids_cap = 0;
     int64_t n_lanes = 0;                 // alignments resident on the device (distinct ones if dedup)
     std::vector<int32_t> rep_of;         // dedup: caller's alignment -> the identical one that is resident
     int32_t *d_slot_orig = nullptr;    // [n_items*64] original index or -1
@@ -1936,6 +2843,7 @@ void free_scorer(gfal_scorer *s)
     if (!s) return;
     (void)hipSetDevice(s->device);
     void *bufs[] = {s->d_item_pairs, s->d_item_pbase, s->d_item_common, s->d_item_hdr, s->d_item_weight,
+                    s->d_item_hash, s->d_item_pairs0, s->d_lids, s->d_segs,
                     s->d_len_bins, s->d_order,
                     s->d_counts_slot,
                     s->d_node_local, s->d_node_hist, s->d_item_steps, s->d_item_base,
@@ -2352,10 +3260,30 @@ static int create_impl(const int32_t *aln_off, const int32_t *aln_steps, int64_t
     std::vector<ItemSrc> src;
     std::vector<uint32_t> item_base, item_pbase;
     std::vector<uint16_t> item_len;
-    uint64_t global_item = 0, n_u16 = 0, n_pairs = 0;
+    uint64_t n_u16 = 0, n_pairs = 0, n_pairs0 = 0;
     int64_t own_aln = n_empty, own_steps = 0, n_lanes = 0;
-    for (int m = 1; m <= max_len; ++m) {
+    // Item order: the well-populated lengths first (k_scan2 builds one window
+    // table per tile and length, which pays from a few dozen items up), then the
+    // rare ones (k_scan).  The shards of one set agree on the order (same input),
+    // and every length deals its own items round robin, so a shard's segment of a
+    // length holds 1/n of that length's items.
+    int hash_min_items = 48;
+    if (const char *env = getenv("GFAL_HASH_MIN_ITEMS")) hash_min_items = std::max(1, atoi(env));
+    std::vector<int> len_order;
+    std::vector<char> is_hash_len((size_t)max_len + 1, 0);
+    for (int m = 1; m <= max_len; ++m)
+        if ((int64_t)by_len[(size_t)m].size() >= (int64_t)hash_min_items * WAVE * n_shards) {
+            is_hash_len[(size_t)m] = 1;
+            len_order.push_back(m);
+        }
+    for (int m = 1; m <= max_len; ++m)
+        if (!is_hash_len[(size_t)m] && !by_len[(size_t)m].empty()) len_order.push_back(m);
+    std::vector<LenSeg> segs;      // one per length, in item order
+    int n_hash_items = 0, n_hash_segs = 0;
+    for (int m : len_order) {
         const std::vector<int32_t> &idx = by_len[(size_t)m];
+        uint64_t global_item = 0;      // of this length
+        const size_t seg_lo = src.size();
         for (size_t at = 0; at < idx.size(); at += WAVE) {
             const size_t cnt = std::min<size_t>(WAVE, idx.size() - at);
             // shards are cut AFTER the global sort, item by item: a shard's items
@@ -2376,8 +3304,18 @@ static int create_impl(const int32_t *aln_off, const int32_t *aln_steps, int64_t
             }
             n_lanes += (int64_t)cnt;
         }
+        if (src.size() > seg_lo) {
+            segs.push_back(LenSeg{(uint32_t)seg_lo, (uint32_t)src.size(), (uint32_t)m, 1u,
+                                  item_base[seg_lo], (uint32_t)(n_pairs0 / WAVE)});
+            n_pairs0 += (uint64_t)(src.size() - seg_lo) * (uint64_t)((m + 1) / 2) * WAVE;
+            if (is_hash_len[(size_t)m]) {
+                n_hash_items = (int)src.size();
+                n_hash_segs = (int)segs.size();
+            }
+        }
     }
-    if (n_u16 / WAVE >= ((uint64_t)1 << 32) || src.size() >= ((size_t)1 << 25)) {
+    if (n_u16 / WAVE >= ((uint64_t)1 << 32) || n_pairs0 / WAVE >= ((uint64_t)1 << 32) ||
+        src.size() >= ((size_t)1 << 25)) {
         set_err("shard too large for 32-bit item addressing");
         return GFAL_E_RANGE;
     }
@@ -2386,6 +3324,14 @@ static int create_impl(const int32_t *aln_off, const int32_t *aln_steps, int64_t
     std::vector<int32_t> slot_orig(src.size() * WAVE, -1);
     std::vector<uint32_t> item_common(src.size(), NO_COMMON_NODE);
     std::vector<uint32_t> item_weight(dedup ? src.size() * WAVE : 0, 0u);
+    std::vector<uint32_t> item_hash(src.size() * WAVE, 0u);
+    std::vector<uint32_t> item_pairs0((size_t)n_pairs0, 0xFFFFFFFFu);
+    // where every item's pairs0 block starts (units of 64 dwords): its segment's base
+    // plus its rank in the segment times ceil(m / 2)
+    std::vector<uint32_t> item_p0base(src.size(), 0u);
+    for (const LenSeg &sg : segs)
+        for (uint32_t it = sg.item_lo; it < sg.item_hi; ++it)
+            item_p0base[it] = sg.p0_base + (it - sg.item_lo) * ((sg.m + 1) / 2);
     {
         unsigned n_threads = std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency()));
         if (const char *env = getenv("GFAL_CREATE_THREADS")) n_threads = (unsigned)std::max(1, atoi(env));
@@ -2404,14 +3350,21 @@ static int create_impl(const int32_t *aln_off, const int32_t *aln_steps, int64_t
                     const uint16_t *px = ls + aln_off[is.idx[l]];
                     const uint32_t w = is.wt ? is.wt[l] : 1u;
                     if (is.wt) item_weight[it * WAVE + (size_t)l] = w;
+                    uint32_t wh = whash_init(m);
                     for (int t = 0; t < m; ++t) {
                         steps[(size_t)t * WAVE + l] = px[t];
                         h[px[t] >> 1] += w;
+                        wh = whash_step(wh, px[t]);
                     }
+                    item_hash[it * WAVE + (size_t)l] = whash_final(wh);
                     for (int k = 0; k < K; ++k)
                         pairs[(size_t)k * WAVE + l] =
                             (uint32_t)px[2 * k + 1] |
                             ((2 * k + 2 < m) ? ((uint32_t)px[2 * k + 2] << 16) : 0u);
+                    uint32_t *pairs0 = item_pairs0.data() + (size_t)item_p0base[it] * WAVE;
+                    for (int k = 0; k < (m + 1) / 2; ++k)
+                        pairs0[(size_t)k * WAVE + l] =
+                            (uint32_t)px[2 * k] | ((2 * k + 1 < m) ? ((uint32_t)px[2 * k + 1] << 16) : 0xFFFF0000u);
                     slot_orig[it * WAVE + (size_t)l] = is.idx[l];
                 }
                 // nodes every lane has: the first and the last such node of lane 0
@@ -2522,6 +3475,12 @@ static int create_impl(const int32_t *aln_off, const int32_t *aln_steps, int64_t
     CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan<true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize,
                                    LDS_BUDGET));
+    CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan2<false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   LDS_BUDGET));
+    CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan2<true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   LDS_BUDGET));
     CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_prep),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
     if ((rc = dev_upload(&s->d_node_local, node_local))) return fail(rc);
@@ -2533,6 +3492,13 @@ static int create_impl(const int32_t *aln_off, const int32_t *aln_steps, int64_t
     if ((rc = dev_upload(&s->d_item_pbase, item_pbase))) return fail(rc);
     if ((rc = dev_upload(&s->d_item_common, item_common))) return fail(rc);
     if (dedup && (rc = dev_upload(&s->d_item_weight, item_weight))) return fail(rc);
+    if ((rc = dev_upload(&s->d_item_hash, item_hash))) return fail(rc);
+    if ((rc = dev_upload(&s->d_item_pairs0, item_pairs0))) return fail(rc);
+    if ((rc = dev_upload(&s->d_segs, segs))) return fail(rc);
+    s->segs = segs;
+    s->n_hash_items = n_hash_items;
+    s->n_hash_segs = n_hash_segs;
+    if (const char *env = getenv("GFAL_SCAN")) s->scan_mode = atoi(env);
     {
         std::vector<uint4> item_hdr(src.size());
         for (size_t it = 0; it < src.size(); ++it)
@@ -2634,6 +3600,12 @@ static int ensure_call_buffers(gfal_scorer *s, int32_t n_paths, const ImageLayou
         if ((rc = dev_reserve(&s->d_counts_slot, &s->counts_slot_cap, (size_t)3 * n_paths)))
             return rc;
     }
+    want = (size_t)n_paths * L.nm;
+    if (want > s->lids_cap) {
+        if (s->have_last) HIP_TRY(hipStreamSynchronize(s->last_stream));
+        int rc = dev_reserve(&s->d_lids, &s->lids_cap, want);
+        if (rc) return rc;
+    }
     return GFAL_OK;
 }
 
@@ -2658,8 +3630,20 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
 
     const ImageLayout L = make_layout(s->n_local, max_path_len);
     const size_t img_bytes = (size_t)L.total * sizeof(uint16_t);
-    if (img_bytes + (size_t)L.v2 * sizeof(uint32_t) > (size_t)LDS_BUDGET) {
-        set_err("path image of %zu bytes exceeds the LDS budget", img_bytes);
+    const size_t mask_bytes = (size_t)L.v2 * sizeof(uint32_t);
+    // k_scan stages whole images (first-occurrence tables included: they grow with
+    // the node count), k_scan2 only steps, node masks and its window table
+    const bool chain_fits = img_bytes + mask_bytes <= (size_t)LDS_BUDGET;
+    const size_t scan2_fixed = mask_bytes + (size_t)H_SLOTS * 5 + 64;
+    const size_t scan2_per_path = (size_t)L.nm * 2 * sizeof(uint16_t);
+    const bool hash_fits = scan2_fixed + scan2_per_path <= (size_t)LDS_BUDGET;
+    if (!chain_fits && !hash_fits) {
+        set_err("%d local nodes and paths of up to %d steps exceed the LDS budget of the scan kernels",
+                s->n_local, (int)max_path_len);
+        return GFAL_E_RANGE;
+    }
+    if (img_bytes + (size_t)L.nm * sizeof(uint16_t) + mask_bytes > (size_t)LDS_MAX) {
+        set_err("%d local nodes exceed the LDS budget of the path preparation", s->n_local);
         return GFAL_E_RANGE;
     }
     {
@@ -2700,7 +3684,7 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
                        d_path_off, d_path_steps, (int)n_paths, total_steps,
                        (int)max_path_len, s->d_node_local, (int)s->n_nodes,
                        s->d_node_hist, (uint32_t)s->n_steps, s->n_empty, filter, L,
-                       s->d_order, s->d_images, d_counts, s->d_status, d_hist);
+                       s->d_order, s->d_images, d_counts, s->d_status, d_hist, s->d_lids);
     HIP_TRY(hipGetLastError());
     if (s->profiling) HIP_TRY(hipEventRecord(ev[1], st));
 
@@ -2708,61 +3692,134 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
     s->last_grid = 0;
     s->last_lds = 0;
     if (s->n_items > 0) {
+        const Items items{s->d_item_steps, s->d_item_base, s->d_item_len, s->d_item_pairs,
+                          s->d_item_pbase, s->n_items, s->d_item_common, s->d_item_hdr, s->d_item_weight};
+        unsigned long long *const wl_count = reinterpret_cast<unsigned long long *>(s->d_status + 2);
+        int want_groups = 8192;
+        if (const char *env = getenv("GFAL_SCAN_GROUPS")) want_groups = std::max(1, atoi(env));
+        const int slots = 2 * s->n_cus;
+        // Which kernel scans what.  k_scan2 (window tables): the segments of the
+        // well-populated lengths -- or all of them when k_scan's images do not fit
+        // (many nodes) or GFAL_SCAN=2 asks; k_scan (occurrence chains): the rest.
+        int n_segs2 = s->n_hash_segs;
+        if (!hash_fits || s->scan_mode == 1) n_segs2 = 0;
+        if (!chain_fits || s->scan_mode == 2) n_segs2 = (int)s->segs.size();
+        if (n_segs2 == 0 && !chain_fits) return GFAL_E_RANGE;
+        const int item_lo_chain = n_segs2 > 0 ? (int)s->segs[(size_t)n_segs2 - 1].item_hi : 0;
+
+        if (n_segs2 > 0) {
+            Scan2Args a2;
+            a2.items = items;
+            a2.item_hash = s->d_item_hash;
+            a2.pairs0 = s->d_item_pairs0;
+            a2.images = s->d_images;
+            a2.L = L;
+            a2.lids = s->d_lids;
+            a2.n_paths = n_paths;
+            int tile = (int)std::min<size_t>(((size_t)LDS_BUDGET - scan2_fixed) / scan2_per_path, TILE2_MAX);
+            tile = std::max(1, std::min(tile, (int)n_paths));
+            a2.tile = tile;
+            a2.n_tiles = (n_paths + tile - 1) / tile;
+            a2.filter = filter ? 1 : 0;
+            a2.debug = getenv("GFAL_DEBUG_SCAN2") ? atoi(getenv("GFAL_DEBUG_SCAN2")) : 0;
+            a2.counts = d_counts;
+            a2.worklist = s->d_worklist;
+            a2.wl_count = wl_count;
+            a2.wl_capacity = s->wl_capacity;
+            a2.wl_hist = d_hist;
+            a2.status = s->d_status;
+            const size_t lds2 = scan2_fixed + (size_t)tile * scan2_per_path;
+            // chunks per segment: in proportion to the segment's items, every
+            // workgroup keeping enough items to pay for its prologue (staging, node
+            // masks, one table insert per window of the tile); small batches trade
+            // that for filling the GPU, as k_scan does
+            const int64_t items2 = item_lo_chain;
+            int y_want = (want_groups + a2.n_tiles - 1) / a2.n_tiles;
+            int min_items = 100 * SCAN_WAVES;
+            if (a2.n_tiles < slots && (long long)a2.n_tiles * y_want < 4LL * slots) {
+                y_want = (4 * slots + a2.n_tiles - 1) / a2.n_tiles;
+                min_items = 12 * SCAN_WAVES;
+            }
+            a2.chunk_mult = (((unsigned long long)y_want << 24) + (unsigned long long)items2 - 1) /
+                            (unsigned long long)std::max<int64_t>(items2, 1);
+            a2.chunk_inv_min = (1ull << 24) / (unsigned long long)min_items;
+            for (int s0 = 0; s0 < n_segs2; s0 += MAX_SEGS) {
+                const int ns = std::min(MAX_SEGS, n_segs2 - s0);
+                a2.segs = s->d_segs + s0;
+                a2.n_segs = ns;
+                unsigned y_total = 0;
+                for (int k = 0; k < ns; ++k) {
+                    const LenSeg &sg = s->segs[(size_t)(s0 + k)];
+                    y_total += seg_chunks(sg.item_hi - sg.item_lo, a2.chunk_mult, a2.chunk_inv_min);
+                }
+                const unsigned grid2 = (unsigned)a2.n_tiles * y_total;
+                if (s->d_item_weight)
+                    hipLaunchKernelGGL(k_scan2<true>, dim3(grid2), dim3(SCAN_THREADS), lds2, st, a2);
+                else
+                    hipLaunchKernelGGL(k_scan2<false>, dim3(grid2), dim3(SCAN_THREADS), lds2, st, a2);
+                HIP_TRY(hipGetLastError());
+                s->last_grid += (int)grid2;
+            }
+            s->last_tile = tile;
+            s->last_lds = (int)lds2;
+        }
+
         ScanArgs a;
-        a.items = Items{s->d_item_steps, s->d_item_base, s->d_item_len, s->d_item_pairs,
-                        s->d_item_pbase, s->n_items, s->d_item_common, s->d_item_hdr, s->d_item_weight};
+        a.items = items;
         a.images = s->d_images;
         a.L = L;
         a.n_paths = n_paths;
-        const size_t mask_bytes = (size_t)L.v2 * sizeof(uint32_t);
-        int tile = (int)std::min<size_t>(((size_t)LDS_BUDGET - mask_bytes) / img_bytes,
-                                         MAX_TILE);
-        tile = std::max(1, std::min(tile, (int)n_paths));
-        a.tile = tile;
-        a.n_tiles = (n_paths + tile - 1) / tile;
-        // enough workgroups to fill 256 CUs x 2 several times over, but every
-        // chunk keeps a few items per wave
-        int want_groups = 8192;
-        if (const char *env = getenv("GFAL_SCAN_GROUPS")) want_groups = std::max(1, atoi(env));
-        int chunks = (want_groups + a.n_tiles - 1) / a.n_tiles;
-        // at least ~100 items per wave and workgroup: every workgroup re-stages its
-        // tile's images, which small shards cannot amortise otherwise, and the
-        // item rejection works on 64 items of a wave at a time
-        const int want_chunks = chunks;
-        const int max_chunks = std::max(1, s->n_items / (100 * SCAN_WAVES));
-        chunks = std::max(1, std::min(chunks, max_chunks));
-        // small batches (what a search submits) end up with about one round of the
-        // 2-per-CU resident workgroups, and tiles of long paths cost more than
-        // tiles of short ones: trade staging for balance down to ~12 items per
-        // wave until there are four rounds, and always fill the first round
-        const int slots = 2 * s->n_cus;
-        if (a.n_tiles < slots && (long long)a.n_tiles * chunks < 4LL * slots) {
-            const int balanced = std::min((4 * slots + a.n_tiles - 1) / a.n_tiles,
-                                          std::max(1, s->n_items / (12 * SCAN_WAVES)));
-            chunks = std::max(chunks, std::min(want_chunks, balanced));
-        }
-        if ((long long)a.n_tiles * chunks < slots)
-            chunks = std::max(chunks, std::min(slots / a.n_tiles,
-                                               std::max(1, s->n_items / SCAN_WAVES)));
-        a.n_chunks = chunks;
         a.filter = filter ? 1 : 0;
         a.counts = d_counts;
         a.worklist = s->d_worklist;
-        a.wl_count = reinterpret_cast<unsigned long long *>(s->d_status + 2);
+        a.wl_count = wl_count;
         a.wl_capacity = s->wl_capacity;
         a.wl_hist = d_hist;
         a.status = s->d_status;
-        const size_t lds = std::max((size_t)tile * img_bytes + mask_bytes,
-                                    (size_t)2 * MAX_TILE * sizeof(uint32_t));
-        const unsigned grid = (unsigned)a.n_tiles * (unsigned)a.n_chunks;
-        if (s->d_item_weight)
-            hipLaunchKernelGGL(k_scan<true>, dim3(grid), dim3(SCAN_THREADS), lds, st, a);
-        else
-            hipLaunchKernelGGL(k_scan<false>, dim3(grid), dim3(SCAN_THREADS), lds, st, a);
-        HIP_TRY(hipGetLastError());
-        s->last_tile = tile;
-        s->last_grid = (int)grid;
-        s->last_lds = (int)lds;
+        a.item_lo = item_lo_chain;
+        const int n_items_chain = s->n_items - item_lo_chain;
+        if (n_items_chain > 0) {
+            int tile = (int)std::min<size_t>(((size_t)LDS_BUDGET - mask_bytes) / img_bytes,
+                                             MAX_TILE);
+            tile = std::max(1, std::min(tile, (int)n_paths));
+            a.tile = tile;
+            a.n_tiles = (n_paths + tile - 1) / tile;
+            // enough workgroups to fill 256 CUs x 2 several times over, but every
+            // chunk keeps a few items per wave
+            int chunks = (want_groups + a.n_tiles - 1) / a.n_tiles;
+            // at least ~100 items per wave and workgroup: every workgroup re-stages its
+            // tile's images, which small shards cannot amortise otherwise, and the
+            // item rejection works on 64 items of a wave at a time
+            const int want_chunks = chunks;
+            const int max_chunks = std::max(1, n_items_chain / (100 * SCAN_WAVES));
+            chunks = std::max(1, std::min(chunks, max_chunks));
+            // small batches (what a search submits) end up with about one round of the
+            // 2-per-CU resident workgroups, and tiles of long paths cost more than
+            // tiles of short ones: trade staging for balance down to ~12 items per
+            // wave until there are four rounds, and always fill the first round
+            if (a.n_tiles < slots && (long long)a.n_tiles * chunks < 4LL * slots) {
+                const int balanced = std::min((4 * slots + a.n_tiles - 1) / a.n_tiles,
+                                              std::max(1, n_items_chain / (12 * SCAN_WAVES)));
+                chunks = std::max(chunks, std::min(want_chunks, balanced));
+            }
+            if ((long long)a.n_tiles * chunks < slots && n_segs2 == 0)
+                chunks = std::max(chunks, std::min(slots / a.n_tiles,
+                                                   std::max(1, n_items_chain / SCAN_WAVES)));
+            a.n_chunks = chunks;
+            const size_t lds = std::max((size_t)tile * img_bytes + mask_bytes,
+                                        (size_t)2 * MAX_TILE * sizeof(uint32_t));
+            const unsigned grid = (unsigned)a.n_tiles * (unsigned)a.n_chunks;
+            if (s->d_item_weight)
+                hipLaunchKernelGGL(k_scan<true>, dim3(grid), dim3(SCAN_THREADS), lds, st, a);
+            else
+                hipLaunchKernelGGL(k_scan<false>, dim3(grid), dim3(SCAN_THREADS), lds, st, a);
+            HIP_TRY(hipGetLastError());
+            if (n_segs2 == 0) {
+                s->last_tile = tile;
+                s->last_lds = (int)lds;
+            }
+            s->last_grid += (int)grid;
+        }
         if (s->profiling) HIP_TRY(hipEventRecord(ev[2], st));
 
         hipLaunchKernelGGL(k_wl_offsets, dim3(N_CLASSES), dim3(1024), 0, st, d_hist, d_offsets,
@@ -3055,7 +4112,7 @@ static int pair_scores_impl(gfal_scorer *s, const int32_t *path_steps, int32_t n
     hipLaunchKernelGGL(k_prep, dim3(1), dim3(PREP_THREADS), prep_lds, s->stream, s->d_path_off,
                        s->d_path_steps, 1, (int64_t)n, (int)n, s->d_node_local,
                        (int)s->n_nodes, s->d_node_hist, (uint32_t)s->n_steps,
-                       s->n_empty, 0, L, nullptr, s->d_images, s->d_counts, s->d_status, nullptr);
+                       s->n_empty, 0, L, nullptr, s->d_images, s->d_counts, s->d_status, nullptr, nullptr);
     HIP_TRY(hipGetLastError());
 
     // device results are indexed like the caller's alignments (all shards)
@@ -3139,6 +4196,25 @@ int gfal_scorer_get_info(gfal_scorer *s, gfal_info *out)
                                s->last_stream));
         HIP_TRY(hipStreamSynchronize(s->last_stream));
         out->dp_pairs = (int64_t)((unsigned long long)host[2] | ((unsigned long long)host[3] << 32));
+#ifdef GFAL_STAMPS
+        {
+            unsigned long long hs[8] = {};
+            (void)hipMemcpyFromSymbol(hs, HIP_SYMBOL(g_stamp_sum), sizeof(hs));
+            const double n = hs[4] ? (double)hs[4] : 1.0;
+            fprintf(stderr, "stamps per item-wave (%llu items): masks %.0f  lookup %.0f (extra probe rounds %.2f)  "
+                            "triage %.0f (entered by %.3f of the items, %.2f lanes each)  counting %.0f cycles\n",
+                    hs[4], hs[0] / n, hs[1] / n, hs[5] / n, hs[2] / n, hs[6] / n, hs[6] ? (double)hs[7] / hs[6] : 0.0,
+                    hs[3] / n);
+            unsigned long long hw[8] = {};
+            (void)hipMemcpyFromSymbol(hw, HIP_SYMBOL(g_stamp_wg), sizeof(hw));
+            const double nw = hw[3] ? (double)hw[3] : 1.0;
+            fprintf(stderr, "per wave (%llu waves, %.2f passes): item loop %.0f cycles, of the rest %.0f: waiting for the "
+                            "workgroup's slowest wave %.0f\n", hw[3], hw[4] / nw, hw[1] / nw, hw[0] / nw, hw[2] / nw);
+            unsigned long long zero[8] = {};
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_sum), zero, sizeof(zero));
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_wg), zero, sizeof(zero));
+        }
+#endif
 #if defined(GFAL_ABLATE) && GFAL_ABLATE == 4
         fprintf(stderr, "chain-loop iterations %u, with a wave-uniform entry %u\n", host[4], host[5]);
 #endif

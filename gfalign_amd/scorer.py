@@ -74,7 +74,8 @@ class ScorerError(RuntimeError):
 
 
 def library_path():
-    return _build.SCORER_SO
+    # GFALIGN_SCORER_SO: an experimental build of the same ABI (scripts/ only)
+    return os.environ.get("GFALIGN_SCORER_SO") or _build.SCORER_SO
 
 
 def load_library():
