@@ -1317,24 +1317,52 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
     return v;
 }
 
+// Steps (idx + 2k, idx + 2k + 1) of the staged steps, packed like an alignment's
+// pair dword: two 32-bit LDS reads + v_alignbit (a ds_read_u16 costs 12-16 LDS
+// cycles per wave-instruction on gfx950, a ds_read_b32 2).
+__device__ __forceinline__ uint32_t window_pair(const uint32_t *step32, uint32_t idx, int k)
+{
+    const uint32_t *w = step32 + (idx >> 1) + k;
+    return __builtin_amdgcn_alignbit(w[1], w[0], idx << 4);
+}
+
 // Prologue: enter the M-step windows of tile path p (both strands) into the table.
+// Tile paths are usually prefixes or siblings of one another.  `lcp[t]` = how many
+// leading steps path t shares with the pass's first path (`base`): a window of
+// path t that lies inside that common prefix IS the base path's window over the
+// same positions, so the base path enters it once with the bits of all the paths
+// that share it, and the other paths enter only their windows beyond the prefix.
 __device__ __forceinline__ void insert_windows(uint16_t *steps, int nm, uint32_t *table,
                                                uint32_t *maskw, uint32_t *used, int p, int n, int M,
-                                               int tid)
+                                               int tid, int base, int n_base, const uint32_t *lcp_all,
+                                               int pass_lo, int pass_hi)
 {
+    const int lcp = p == base ? 0 : (int)lcp_all[p];
+    const uint32_t *step32 = reinterpret_cast<const uint32_t *>(steps);
     const int n_win = n - M + 1;                 // windows per strand
+    const int P0 = (M + 1) / 2;
     uint32_t fresh = 0;                          // entries this thread created
     for (int w = tid; w < 2 * n_win; w += SCAN_THREADS) {
         const uint32_t strand = w >= n_win ? 1u : 0u;
         const uint32_t pos = (uint32_t)(strand ? w - n_win : w);
         const uint32_t idx = ((uint32_t)p * 2u + strand) * (uint32_t)nm + pos;
-        const uint16_t *win = steps + idx;
+        const int x = strand ? n - (int)pos - M : (int)pos;          // first path position covered
+        if (base >= 0 && p != base && x + M <= lcp) continue;        // the base path's window: entered there
+        uint32_t bits = 1u << p;
+        if (p == base)
+            for (int t = pass_lo; t < pass_hi; ++t)
+                bits |= (t != base && x + M <= (int)lcp_all[t]) ? (1u << t) : 0u;
         uint32_t h = whash_init(M);
         bool real = true;
-        for (int t = 0; t < M; ++t) {
-            const uint32_t c = win[t];
-            real &= c < STEP_NOMATCH;            // a step that equals nothing: no alignment matches
-            h = whash_step(h, c);
+        for (int k = 0; k < P0; ++k) {
+            const uint32_t d = window_pair(step32, idx, k);
+            const uint32_t lo = d & 0xFFFFu, hi = d >> 16;
+            real &= lo < STEP_NOMATCH;           // a step that equals nothing: no alignment matches
+            h = whash_step(h, lo);
+            if (2 * k + 1 < M) {
+                real &= hi < STEP_NOMATCH;
+                h = whash_step(h, hi);
+            }
         }
         if (!real) continue;
         h = whash_final(h);
@@ -1348,19 +1376,35 @@ __device__ __forceinline__ void insert_windows(uint16_t *steps, int nm, uint32_t
                 break;
             }
             if (((old ^ h) >> H_FP_SHIFT) == 0u) {      // same fingerprint: the same window?
-                const uint16_t *rep = steps + (old & ((1u << H_FP_SHIFT) - 1u));
+                const uint32_t rep = old & ((1u << H_FP_SHIFT) - 1u);
                 bool same = true;
-                for (int t = 0; t < M; ++t) same &= rep[t] == win[t];
+                for (int k = 0; k < P0; ++k) {
+                    const uint32_t mask = (2 * k + 1 < M) ? 0xFFFFFFFFu : 0xFFFFu;
+                    same &= ((window_pair(step32, rep, k) ^ window_pair(step32, idx, k)) & mask) == 0u;
+                }
                 if (same) break;
             }
             slot = (slot + stride) & (H_SLOTS - 1u);
         }
-        atomicOr(&maskw[slot >> 2], (1u << p) << ((slot & 3u) * 8u));
+        atomicOr(&maskw[slot >> 2], bits << ((slot & 3u) * 8u));
     }
     // one add per wave (64 lanes on one LDS word serialise)
     fresh = wave_sum_u32(fresh);
     if ((tid & (WAVE - 1)) == 0 && fresh) {
         if (atomicAdd(used, fresh) + fresh > (uint32_t)H_CAP) used[1] = 1u;     // overflow: see k_scan2
+    }
+}
+
+// How many leading steps tile paths p and q share (both strands staged: the
+// forward one is compared), left in *out (LDS, preset to min(n_p, n_q)).
+__device__ __forceinline__ void common_prefix(const uint16_t *steps, int nm, int p, int q, int n,
+                                              uint32_t *out, int tid)
+{
+    const uint32_t *a = reinterpret_cast<const uint32_t *>(steps + (size_t)p * 2 * nm);
+    const uint32_t *b = reinterpret_cast<const uint32_t *>(steps + (size_t)q * 2 * nm);
+    for (int i = tid; 2 * i < n; i += SCAN_THREADS) {
+        const uint32_t x = a[i] ^ b[i];
+        if (x) atomicMin(out, (uint32_t)(2 * i + ((x & 0xFFFFu) ? 0 : 1)));
     }
 }
 
@@ -1764,59 +1808,134 @@ __global__ __launch_bounds__(SCAN_THREADS, 6) void k_scan2(Scan2Args a)
     tv.table = table;
     tv.maskb = reinterpret_cast<const uint8_t *>(maskw);
 
-    // stage the steps of the tile's paths (forward | reverse complement: contiguous
-    // in the image, 4-byte aligned) and start the node masks
-    for (int p = 0; p < tv.tile_paths; ++p) {
+    // Stage the steps of the tile's paths (forward | reverse complement: contiguous
+    // in the image, 4-byte aligned) and build the node masks from the node ids along
+    // the paths.  Every global load of the prologue is issued before the first one is
+    // waited for: SCAN_THREADS / TILE2_MAX threads per path, each with its share of
+    // the path's dwords in registers (one exposed memory latency, not one per loop
+    // trip and path).
+    constexpr int PER_PATH = SCAN_THREADS / TILE2_MAX;                   // 96 threads
+    constexpr int STEP_LOADS = (GFAL_MAX_STEPS + 8 + PER_PATH - 1) / PER_PATH;          // nm dwords
+    constexpr int LID_LOADS = ((GFAL_MAX_STEPS + 8) / 2 + PER_PATH - 1) / PER_PATH;     // nm / 2 dwords
+    const int my_p = tid / PER_PATH, my_q = tid % PER_PATH;
+    const bool have_p = my_p < tv.tile_paths;
+    uint32_t sreg[STEP_LOADS], lreg[LID_LOADS];
+    {
         const uint32_t *src = reinterpret_cast<const uint32_t *>(
-            a.images + (size_t)(tv.path0 + p) * a.L.total + a.L.step_at());
-        uint32_t *dst = reinterpret_cast<uint32_t *>(steps + (size_t)p * 2 * nm);
-        for (int i = tid; i < nm; i += SCAN_THREADS) dst[i] = src[i];
-    }
-    for (int v = tid; v < a.L.v2; v += SCAN_THREADS) nodemask[v] = NOT_A0;
-    tv.hdr_n = 0;
-    tv.hdr_a0 = STEP_NOMATCH;
-    if (lane < tv.tile_paths) {
-        const uint16_t *img = a.images + (size_t)(tv.path0 + lane) * a.L.total;
-        tv.hdr_n = img[a.L.len_at()];
-        tv.hdr_a0 = img[a.L.step_at()];
-    }
-    const uint32_t tile_a0 = (uint32_t)__builtin_amdgcn_readlane((int)tv.hdr_a0, 0);
-    tv.uniform_a0 = WAVE_MASK(lane < tv.tile_paths && tv.hdr_a0 != tile_a0) == 0ull;
-    __syncthreads();
-    // which tile paths carry each node (the filter of src/eval.cpp:81-91 as a bit
-    // test); the node of the tile's first step loses NOT_A0
-    for (int p = 0; p < tv.tile_paths; ++p) {
-        const int n = __builtin_amdgcn_readlane(tv.hdr_n, p);
-        const uint16_t *lid = a.lids + (size_t)(tv.path0 + p) * nm;
-        for (int i = tid; i < n; i += SCAN_THREADS) {
-            const uint32_t v = lid[i];
-            if (v != 0xFFFFu) atomicOr(&nodemask[v], 1u << p);
+            a.images + (size_t)(tv.path0 + (have_p ? my_p : 0)) * a.L.total + a.L.step_at());
+        const uint32_t *lsrc = reinterpret_cast<const uint32_t *>(
+            a.lids + (size_t)(tv.path0 + (have_p ? my_p : 0)) * nm);
+#pragma unroll
+        for (int k = 0; k < STEP_LOADS; ++k) {
+            const int o = my_q + k * PER_PATH;
+            sreg[k] = (have_p && o < nm) ? src[o] : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int k = 0; k < LID_LOADS; ++k) {
+            const int o = my_q + k * PER_PATH;
+            lreg[k] = (have_p && o < nm / 2) ? lsrc[o] : 0xFFFFFFFFu;
         }
     }
+    tv.hdr_n = 0;
+    if (lane < tv.tile_paths)
+        tv.hdr_n = a.images[(size_t)(tv.path0 + lane) * a.L.total + a.L.len_at()];
+    // meanwhile: node masks, table and counters start empty
+    for (int v = tid; v < a.L.v2; v += SCAN_THREADS) nodemask[v] = NOT_A0;
+    for (int i = tid; i < H_SLOTS; i += SCAN_THREADS) table[i] = H_EMPTY;
+    for (int i = tid; i < H_SLOTS / 4; i += SCAN_THREADS) maskw[i] = 0;
+    if (tid < 16) misc[tid] = 0;               // [0] entries, [1] overflow flag, [2 + t] common prefixes
+    __syncthreads();
+    if (have_p) {
+        uint32_t *dst = reinterpret_cast<uint32_t *>(steps + (size_t)my_p * 2 * nm);
+#pragma unroll
+        for (int k = 0; k < STEP_LOADS; ++k) {
+            const int o = my_q + k * PER_PATH;
+            if (o < nm) dst[o] = sreg[k];
+        }
+        // which tile paths carry each node (the filter of src/eval.cpp:81-91 as a bit test)
+#pragma unroll
+        for (int k = 0; k < LID_LOADS; ++k) {
+            const uint32_t lo = lreg[k] & 0xFFFFu, hi = lreg[k] >> 16;
+            if (lo != 0xFFFFu) atomicOr(&nodemask[lo], 1u << my_p);
+            if (hi != 0xFFFFu) atomicOr(&nodemask[hi], 1u << my_p);
+        }
+    }
+    __syncthreads();
+    // the tiles's first steps; the node of path 0's first step loses NOT_A0
+    tv.hdr_a0 = STEP_NOMATCH;
+    if (lane < tv.tile_paths) tv.hdr_a0 = steps[(size_t)lane * 2 * nm];
+    const uint32_t tile_a0 = (uint32_t)__builtin_amdgcn_readlane((int)tv.hdr_a0, 0);
+    tv.uniform_a0 = WAVE_MASK(lane < tv.tile_paths && tv.hdr_a0 != tile_a0) == 0ull;
     if (tid == 0 && tile_a0 < STEP_NOMATCH) atomicAnd(&nodemask[tile_a0 >> 1], ~NOT_A0);
     __syncthreads();
+#ifdef GFAL_STAMPS
+    unsigned long long pg1, pg2, pg3;
+    STAMP(pg1);
+    if (lane == 0) atomicAdd(&g_stamp_wg[5], pg1 - wg0);      // staging + node masks
+#endif
 
     uint32_t cnt_good = 0, cnt_bad = 0;      // lane p: totals of tile path p over all passes
     // passes over the tile's paths: as many paths per pass as fit the table
     int t0 = 0;
+    bool fresh_table = true;                   // the prologue has just cleared it
     while (t0 < tv.tile_paths) {
         int t1 = t0, limit = tv.tile_paths;
         uint32_t gt_mask = 0;
-        while (true) {                         // second round only after an overflow
+        bool one_by_one = false;
+        while (true) {                         // further rounds only after an overflow
             __syncthreads();
-            for (int i = tid; i < H_SLOTS; i += SCAN_THREADS) table[i] = H_EMPTY;
-            for (int i = tid; i < H_SLOTS / 4; i += SCAN_THREADS) maskw[i] = 0;
-            if (tid < 2) misc[tid] = 0;        // [0] entries, [1] overflow flag
+            if (!fresh_table) {
+                for (int i = tid; i < H_SLOTS; i += SCAN_THREADS) table[i] = H_EMPTY;
+                for (int i = tid; i < H_SLOTS / 4; i += SCAN_THREADS) maskw[i] = 0;
+                if (tid < 2) misc[tid] = 0;    // [0] entries, [1] overflow flag
+            }
+            fresh_table = false;
+            // the first path of the pass that has windows, and what the others share with it
+            int base = -1, n_base = 0;
+            for (int t = t0; t < limit; ++t) {
+                const int n = __builtin_amdgcn_readlane(tv.hdr_n, t);
+                if (n >= M && base < 0) {
+                    base = t;
+                    n_base = n;
+                }
+                if (tid == 0) misc[2 + t] = (uint32_t)min(n, n_base);     // [2 + t]: common prefix with base
+            }
             __syncthreads();
+            for (int t = base + 1; base >= 0 && t < limit; ++t) {
+                const int n = __builtin_amdgcn_readlane(tv.hdr_n, t);
+                if (n >= M) common_prefix(steps, nm, base, t, min(n, n_base), &misc[2 + t], tid);
+            }
+            __syncthreads();
+#ifdef GFAL_STAMPS
+            STAMP(pg2);
+            if (lane == 0) atomicAdd(&g_stamp_wg[6], pg2 - pg1);      // table clear + common prefixes
+#endif
             t1 = t0;
             gt_mask = 0;
             bool overflow = false;
+            if (!one_by_one) {
+                // all paths of the pass at once, no barrier between them (similar paths
+                // share their windows: this nearly always fits); if it does not, the
+                // table is rebuilt path by path to find out how many do fit
+                for (; t1 < limit; ++t1) {
+                    const int n = __builtin_amdgcn_readlane(tv.hdr_n, t1);
+                    if (n < M) gt_mask |= 1u << t1;      // no windows: every passing alignment is good
+                    else
+                        insert_windows(steps, nm, table, maskw, misc, t1, n, M, tid, base, n_base,
+                                       misc + 2, t0, limit);
+                }
+                __syncthreads();
+                if (misc[1] == 0u) break;
+                one_by_one = true;
+                continue;
+            }
             while (t1 < limit) {
                 const int n = __builtin_amdgcn_readlane(tv.hdr_n, t1);
                 if (n < M) {
-                    gt_mask |= 1u << t1;      // no windows: every passing alignment is good
+                    gt_mask |= 1u << t1;
                 } else {
-                    insert_windows(steps, nm, table, maskw, misc, t1, n, M, tid);
+                    insert_windows(steps, nm, table, maskw, misc, t1, n, M, tid, -1, 0, misc + 2, t0,
+                                   t1 + 1);          // (no sharing: the pass's extent is not known yet)
                     __syncthreads();
                     overflow = misc[1] != 0u;
                     if (overflow) break;
@@ -1835,6 +1954,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 6) void k_scan2(Scan2Args a)
 
 #ifdef GFAL_STAMPS
         STAMP(wg1);
+        if (lane == 0) atomicAdd(&g_stamp_wg[7], wg1 - pg2);          // window inserts
 #endif
         LenSeg sgl = sg;
         if (a.debug == 1) sgl.item_hi = sgl.item_lo;      // timing probe: no items
@@ -3702,6 +3822,11 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
         // well-populated lengths -- or all of them when k_scan's images do not fit
         // (many nodes) or GFAL_SCAN=2 asks; k_scan (occurrence chains): the rest.
         int n_segs2 = s->n_hash_segs;
+        // a batch of a few dozen paths is one or two tiles: k_scan2's per-workgroup
+        // prologue (staging, node masks, the tile's windows into the table) is then
+        // the whole latency (0.20 ms at 8 paths against 0.04 ms), above ~100 paths it
+        // is ahead (scripts/small_batch_probe.py)
+        if (n_paths < 96) n_segs2 = 0;
         if (!hash_fits || s->scan_mode == 1) n_segs2 = 0;
         if (!chain_fits || s->scan_mode == 2) n_segs2 = (int)s->segs.size();
         if (n_segs2 == 0 && !chain_fits) return GFAL_E_RANGE;
@@ -3736,8 +3861,8 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
             const int64_t items2 = item_lo_chain;
             int y_want = (want_groups + a2.n_tiles - 1) / a2.n_tiles;
             int min_items = 100 * SCAN_WAVES;
-            if (a2.n_tiles < slots && (long long)a2.n_tiles * y_want < 4LL * slots) {
-                y_want = (4 * slots + a2.n_tiles - 1) / a2.n_tiles;
+            if (a2.n_tiles < slots) {          // fewer tiles than resident workgroups: fill the GPU
+                y_want = std::min(y_want, (4 * slots + a2.n_tiles - 1) / a2.n_tiles);
                 min_items = 12 * SCAN_WAVES;
             }
             a2.chunk_mult = (((unsigned long long)y_want << 24) + (unsigned long long)items2 - 1) /
@@ -4209,7 +4334,8 @@ int gfal_scorer_get_info(gfal_scorer *s, gfal_info *out)
             (void)hipMemcpyFromSymbol(hw, HIP_SYMBOL(g_stamp_wg), sizeof(hw));
             const double nw = hw[3] ? (double)hw[3] : 1.0;
             fprintf(stderr, "per wave (%llu waves, %.2f passes): item loop %.0f cycles, of the rest %.0f: waiting for the "
-                            "workgroup's slowest wave %.0f\n", hw[3], hw[4] / nw, hw[1] / nw, hw[0] / nw, hw[2] / nw);
+                            "workgroup's slowest wave %.0f, staging + node masks %.0f, clear + prefixes %.0f, inserts %.0f\n",
+                    hw[3], hw[4] / nw, hw[1] / nw, hw[0] / nw, hw[2] / nw, hw[5] / nw, hw[6] / nw, hw[7] / nw);
             unsigned long long zero[8] = {};
             (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_sum), zero, sizeof(zero));
             (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_wg), zero, sizeof(zero));
