@@ -1213,6 +1213,19 @@ struct StampAcc {
 #define STAMP_ACC
 #endif
 
+// Node masks are 32 bits per node (bits 0..7: the tile paths, bit 31: NOT_A0), or
+// -- NM8, tangles of many nodes: 4 bytes per node would not leave room for the
+// paths -- one byte per node (bits 0..6: at most 7 tile paths, bit 7: NOT_A0; a
+// ds_read_u8 costs 6-8x a ds_read_b32 on gfx950, so only then).
+template <bool NM8>
+__device__ __forceinline__ uint32_t node_mask(const Tile2 &tv, uint32_t node)
+{
+    if constexpr (NM8) return reinterpret_cast<const uint8_t *>(tv.nodemask)[node];
+    else return tv.nodemask[node];
+}
+constexpr uint32_t NOT_A0_8 = 0x80u;
+constexpr int TILE2_MAX_NM8 = 7;
+
 // lane p: totals of tile path p; all lanes: byte p of packed_* counts this
 // lane's alignments for tile path p since the last flush (< 256 items)
 struct WaveCounts2 {
@@ -1369,10 +1382,21 @@ __device__ __forceinline__ void insert_windows(uint16_t *steps, int nm, uint32_t
         const uint32_t want = (h & ~((1u << H_FP_SHIFT) - 1u)) | idx;
         uint32_t slot = h & (H_SLOTS - 1u);
         const uint32_t stride = ((h >> H_LOG_S) & (H_SLOTS - 1u)) | 1u;
-        while (true) {
+        // Entries are counted when the call ends; a table that fills up meanwhile
+        // (unrelated paths entered together) shows in the probe length: at a load of
+        // 1/2 a run of 48 occupied slots has probability 2^-48, so such a run means
+        // overflow -- flag it and stop (the caller rebuilds the table path by path).
+        int probes = 0;
+        bool gave_up = used[1] != 0u;
+        while (!gave_up) {
             const uint32_t old = atomicCAS(&table[slot], H_EMPTY, want);
             if (old == H_EMPTY) {
                 ++fresh;
+                break;
+            }
+            if (++probes > 48) {
+                used[1] = 1u;
+                gave_up = true;
                 break;
             }
             if (((old ^ h) >> H_FP_SHIFT) == 0u) {      // same fingerprint: the same window?
@@ -1386,6 +1410,7 @@ __device__ __forceinline__ void insert_windows(uint16_t *steps, int nm, uint32_t
             }
             slot = (slot + stride) & (H_SLOTS - 1u);
         }
+        if (gave_up) break;
         atomicOr(&maskw[slot >> 2], bits << ((slot & 3u) * 8u));
     }
     // one add per wave (64 lanes on one LDS word serialise)
@@ -1418,7 +1443,7 @@ struct ItemRegs {
     uint32_t it;             // (uniform) the item
 };
 
-template <int P0, int MC, bool W, typename Counts>
+template <int P0, int MC, bool W, bool NM8, typename Counts>
 __device__ __forceinline__ void scan2_item(const Scan2Args &a, const Tile2 &tv, const LenSeg &sg,
                                            const ItemRegs<P0> &r, int M_rt, int lane, Counts &wc)
 {
@@ -1450,12 +1475,12 @@ __device__ __forceinline__ void scan2_item(const Scan2Args &a, const Tile2 &tv, 
     uint32_t pm = 0xFFFFFFFFu;
 #pragma unroll
     for (int k = 0; k < P0; ++k) {
-        pm &= tv.nodemask[(p0[k] & 0xFFFFu) >> 1];
-        if (k + 1 < P0 || !(M & 1)) pm &= tv.nodemask[p0[k] >> 17];
+        pm &= node_mask<NM8>(tv, (p0[k] & 0xFFFFu) >> 1);
+        if (k + 1 < P0 || !(M & 1)) pm &= node_mask<NM8>(tv, p0[k] >> 17);
     }
     uint32_t pass = a.filter ? pm : 0xFFu;
     pass = valid ? (pass & tv.sub_mask) : 0u;
-    const bool has_a0 = !tv.uniform_a0 || (pm & NOT_A0) == 0u;
+    const bool has_a0 = !tv.uniform_a0 || (pm & (NM8 ? NOT_A0_8 : NOT_A0)) == 0u;
     const uint32_t gt = pass & tv.gt_mask;          // src/alignments.cpp:500: m > n -> good
     const uint32_t todo = pass & ~tv.gt_mask;
 #ifdef GFAL_STAMPS
@@ -1596,7 +1621,7 @@ __device__ __forceinline__ void scan2_item(const Scan2Args &a, const Tile2 &tv, 
 
 // The same for alignments too long for registers (M > 2 * MAX_REG_K + 1): steps are
 // re-read from the item where needed.
-template <bool W, typename Counts>
+template <bool W, bool NM8, typename Counts>
 __device__ __forceinline__ void scan2_item_long(const Scan2Args &a, const Tile2 &tv,
                                                 const uint16_t *__restrict__ bp, uint32_t h, int M,
                                                 int lane, uint32_t slot_id, Counts &wc, uint32_t w)
@@ -1606,11 +1631,11 @@ __device__ __forceinline__ void scan2_item_long(const Scan2Args &a, const Tile2 
     uint32_t pm = 0xFFFFFFFFu;
     for (int t = 0; t < M; ++t) {
         const uint32_t bt = valid ? (uint32_t)bp[t * WAVE] : 0u;
-        pm &= tv.nodemask[bt >> 1];
+        pm &= node_mask<NM8>(tv, bt >> 1);
     }
     uint32_t pass = a.filter ? pm : 0xFFu;
     pass = valid ? (pass & tv.sub_mask) : 0u;
-    const bool has_a0 = !tv.uniform_a0 || (pm & NOT_A0) == 0u;
+    const bool has_a0 = !tv.uniform_a0 || (pm & (NM8 ? NOT_A0_8 : NOT_A0)) == 0u;
     const uint32_t gt = pass & tv.gt_mask;
     const uint32_t todo = pass & ~tv.gt_mask;
     uint32_t fmask = 0;
@@ -1667,7 +1692,7 @@ __device__ __forceinline__ void scan2_item_long(const Scan2Args &a, const Tile2 
 // The wave's items of one segment chunk, 64 at a time (as in k_scan: one ballot
 // drops the items none of whose lanes can pass the filter).  P0 = ceil(M / 2)
 // pair dwords per lane in registers, or -1: long alignments.
-template <int P0, int MC, bool W, typename Counts>
+template <int P0, int MC, bool W, bool NM8, typename Counts>
 __device__ __forceinline__ void scan2_items(const Scan2Args &a, const Tile2 &tv, const LenSeg &sg,
                                             int chunk, int wave, int lane, Counts &wc)
 {
@@ -1683,7 +1708,7 @@ __device__ __forceinline__ void scan2_items(const Scan2Args &a, const Tile2 &tv,
         if (a.filter && mine) {
             const uint32_t common = a.items.common[my_it];
             if (common != NO_COMMON_NODE) {
-                const uint32_t m1 = tv.nodemask[common & 0x7FFFu], m2 = tv.nodemask[common >> 16];
+                const uint32_t m1 = node_mask<NM8>(tv, common & 0x7FFFu), m2 = node_mask<NM8>(tv, common >> 16);
                 keep = (((common & COMMON_EITHER) ? (m1 | m2) : (m1 & m2)) & tv.sub_mask) != 0u;
             }
         }
@@ -1711,12 +1736,12 @@ __device__ __forceinline__ void scan2_items(const Scan2Args &a, const Tile2 &tv,
             while (true) {
                 lanemask rest = todo & (todo - 1);
                 load_item(__builtin_ctzll(rest ? rest : todo), rb);
-                scan2_item<P0, MC, W>(a, tv, sg, ra, M, lane, wc);
+                scan2_item<P0, MC, W, NM8>(a, tv, sg, ra, M, lane, wc);
                 if (rest == 0) break;
                 todo = rest;
                 rest = todo & (todo - 1);
                 load_item(__builtin_ctzll(rest ? rest : todo), ra);
-                scan2_item<P0, MC, W>(a, tv, sg, rb, M, lane, wc);
+                scan2_item<P0, MC, W, NM8>(a, tv, sg, rb, M, lane, wc);
                 if (rest == 0) break;
                 todo = rest;
             }
@@ -1729,7 +1754,7 @@ __device__ __forceinline__ void scan2_items(const Scan2Args &a, const Tile2 &tv,
                 if constexpr (P0 < 0) {
                     const uint16_t *bp = a.items.steps +
                                          ((size_t)sg.step_base + (size_t)(it - sg.item_lo) * (uint32_t)M) * WAVE + ulane;
-                    scan2_item_long<W>(a, tv, bp, h, M, lane, it * WAVE + ulane, wc, w);
+                    scan2_item_long<W, NM8>(a, tv, bp, h, M, lane, it * WAVE + ulane, wc, w);
                 } else {
                     ItemRegs<P0> r;
                     r.it = it;
@@ -1738,7 +1763,7 @@ __device__ __forceinline__ void scan2_items(const Scan2Args &a, const Tile2 &tv,
                     const uint32_t *pp = a.pairs0 + ((size_t)sg.p0_base + (size_t)(it - sg.item_lo) * P0) * WAVE + ulane;
 #pragma unroll
                     for (int k = 0; k < P0; ++k) r.p0[k] = pp[k * WAVE];
-                    scan2_item<P0, MC, W>(a, tv, sg, r, M, lane, wc);
+                    scan2_item<P0, MC, W, NM8>(a, tv, sg, r, M, lane, wc);
                 }
             }
         }
@@ -1750,7 +1775,7 @@ __device__ __forceinline__ void scan2_items(const Scan2Args &a, const Tile2 &tv,
 #endif
 }
 
-template <bool W>
+template <bool W, bool NM8>
 __global__ __launch_bounds__(SCAN_THREADS, 6) void k_scan2(Scan2Args a)
 {
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
@@ -1800,7 +1825,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 6) void k_scan2(Scan2Args a)
     const int nm = a.L.nm;
     uint16_t *steps = lds;                                          // [tile][2][nm]
     uint32_t *nodemask = reinterpret_cast<uint32_t *>(lds + (size_t)a.tile * 2 * nm);
-    uint32_t *table = nodemask + a.L.v2;
+    uint32_t *table = nodemask + (NM8 ? (a.L.v2 + 3) / 4 : a.L.v2);
     uint32_t *maskw = table + H_SLOTS;                              // H_SLOTS bytes
     uint32_t *misc = maskw + H_SLOTS / 4;                           // [0]: entries in the table
     tv.steps = steps;
@@ -1814,7 +1839,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 6) void k_scan2(Scan2Args a)
     // waited for: SCAN_THREADS / TILE2_MAX threads per path, each with its share of
     // the path's dwords in registers (one exposed memory latency, not one per loop
     // trip and path).
-    constexpr int PER_PATH = SCAN_THREADS / TILE2_MAX;                   // 96 threads
+    constexpr int PER_PATH = SCAN_THREADS / TILE2_MAX;                   // 96 threads (NM8: 7 paths use them)
     constexpr int STEP_LOADS = (GFAL_MAX_STEPS + 8 + PER_PATH - 1) / PER_PATH;          // nm dwords
     constexpr int LID_LOADS = ((GFAL_MAX_STEPS + 8) / 2 + PER_PATH - 1) / PER_PATH;     // nm / 2 dwords
     const int my_p = tid / PER_PATH, my_q = tid % PER_PATH;
@@ -1840,7 +1865,11 @@ __global__ __launch_bounds__(SCAN_THREADS, 6) void k_scan2(Scan2Args a)
     if (lane < tv.tile_paths)
         tv.hdr_n = a.images[(size_t)(tv.path0 + lane) * a.L.total + a.L.len_at()];
     // meanwhile: node masks, table and counters start empty
-    for (int v = tid; v < a.L.v2; v += SCAN_THREADS) nodemask[v] = NOT_A0;
+    if constexpr (NM8) {
+        for (int v = tid; v < (a.L.v2 + 3) / 4; v += SCAN_THREADS) nodemask[v] = NOT_A0_8 * 0x01010101u;
+    } else {
+        for (int v = tid; v < a.L.v2; v += SCAN_THREADS) nodemask[v] = NOT_A0;
+    }
     for (int i = tid; i < H_SLOTS; i += SCAN_THREADS) table[i] = H_EMPTY;
     for (int i = tid; i < H_SLOTS / 4; i += SCAN_THREADS) maskw[i] = 0;
     if (tid < 16) misc[tid] = 0;               // [0] entries, [1] overflow flag, [2 + t] common prefixes
@@ -1856,8 +1885,13 @@ __global__ __launch_bounds__(SCAN_THREADS, 6) void k_scan2(Scan2Args a)
 #pragma unroll
         for (int k = 0; k < LID_LOADS; ++k) {
             const uint32_t lo = lreg[k] & 0xFFFFu, hi = lreg[k] >> 16;
-            if (lo != 0xFFFFu) atomicOr(&nodemask[lo], 1u << my_p);
-            if (hi != 0xFFFFu) atomicOr(&nodemask[hi], 1u << my_p);
+            if constexpr (NM8) {
+                if (lo != 0xFFFFu) atomicOr(&nodemask[lo >> 2], (1u << my_p) << ((lo & 3u) * 8u));
+                if (hi != 0xFFFFu) atomicOr(&nodemask[hi >> 2], (1u << my_p) << ((hi & 3u) * 8u));
+            } else {
+                if (lo != 0xFFFFu) atomicOr(&nodemask[lo], 1u << my_p);
+                if (hi != 0xFFFFu) atomicOr(&nodemask[hi], 1u << my_p);
+            }
         }
     }
     __syncthreads();
@@ -1866,7 +1900,11 @@ __global__ __launch_bounds__(SCAN_THREADS, 6) void k_scan2(Scan2Args a)
     if (lane < tv.tile_paths) tv.hdr_a0 = steps[(size_t)lane * 2 * nm];
     const uint32_t tile_a0 = (uint32_t)__builtin_amdgcn_readlane((int)tv.hdr_a0, 0);
     tv.uniform_a0 = WAVE_MASK(lane < tv.tile_paths && tv.hdr_a0 != tile_a0) == 0ull;
-    if (tid == 0 && tile_a0 < STEP_NOMATCH) atomicAnd(&nodemask[tile_a0 >> 1], ~NOT_A0);
+    if (tid == 0 && tile_a0 < STEP_NOMATCH) {
+        const uint32_t v = tile_a0 >> 1;
+        if constexpr (NM8) atomicAnd(&nodemask[v >> 2], ~(NOT_A0_8 << ((v & 3u) * 8u)));
+        else atomicAnd(&nodemask[v], ~NOT_A0);
+    }
     __syncthreads();
 #ifdef GFAL_STAMPS
     unsigned long long pg1, pg2, pg3;
@@ -1963,13 +2001,13 @@ __global__ __launch_bounds__(SCAN_THREADS, 6) void k_scan2(Scan2Args a)
     do {                                                                        \
         if constexpr (W) {                                                      \
             WaveCounts2W wc;                                                    \
-            scan2_items<KK, MM, true>(a, tv, sgl, chunk, wave, lane, wc);       \
+            scan2_items<KK, MM, true, NM8>(a, tv, sgl, chunk, wave, lane, wc);       \
             wc.flush();                                                         \
             cnt_good += wc.good;                                                \
             cnt_bad += wc.bad;                                                  \
         } else {                                                                \
             WaveCounts2 wc;                                                     \
-            scan2_items<KK, MM, false>(a, tv, sgl, chunk, wave, lane, wc);      \
+            scan2_items<KK, MM, false, NM8>(a, tv, sgl, chunk, wave, lane, wc);      \
             wc.flush();                                                         \
             cnt_good += wc.good;                                                \
             cnt_bad += wc.bad;                                                  \
@@ -3595,12 +3633,14 @@ static int create_impl(const int32_t *aln_off, const int32_t *aln_steps, int64_t
     CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan<true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize,
                                    LDS_BUDGET));
-    CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan2<false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   LDS_BUDGET));
-    CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan2<true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   LDS_BUDGET));
+    CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan2<false, false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET));
+    CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan2<true, false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET));
+    CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan2<false, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET));
+    CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan2<true, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET));
     CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_prep),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
     if ((rc = dev_upload(&s->d_node_local, node_local))) return fail(rc);
@@ -3754,9 +3794,22 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
     // k_scan stages whole images (first-occurrence tables included: they grow with
     // the node count), k_scan2 only steps, node masks and its window table
     const bool chain_fits = img_bytes + mask_bytes <= (size_t)LDS_BUDGET;
-    const size_t scan2_fixed = mask_bytes + (size_t)H_SLOTS * 5 + 64;
+    // (node masks of 32 bits per node, or -- many nodes -- of 8: see node_mask())
     const size_t scan2_per_path = (size_t)L.nm * 2 * sizeof(uint16_t);
-    const bool hash_fits = scan2_fixed + scan2_per_path <= (size_t)LDS_BUDGET;
+    const size_t scan2_fixed32 = mask_bytes + (size_t)H_SLOTS * 5 + 64;
+    const size_t scan2_fixed8 = (((size_t)L.v2 + 3) & ~(size_t)3) + (size_t)H_SLOTS * 5 + 64;
+    auto tile_for = [&](size_t fixed, int cap) {
+        return fixed + scan2_per_path > (size_t)LDS_BUDGET
+                   ? 0
+                   : (int)std::min<size_t>(((size_t)LDS_BUDGET - fixed) / scan2_per_path, (size_t)cap);
+    };
+    const int tile32 = tile_for(scan2_fixed32, TILE2_MAX), tile8 = tile_for(scan2_fixed8, TILE2_MAX_NM8);
+    // byte reads from LDS are slow, a smaller tile is slower still (config 5, 5 000 nodes:
+    // 7 paths per tile with byte masks 19.6 ms, 5 paths with 32-bit masks 26.7 ms)
+    bool nm8 = tile8 > tile32;
+    if (const char *env = getenv("GFAL_NM8")) nm8 = atoi(env) != 0 && tile8 > 0;
+    const size_t scan2_fixed = nm8 ? scan2_fixed8 : scan2_fixed32;
+    const bool hash_fits = (nm8 ? tile8 : tile32) > 0;
     if (!chain_fits && !hash_fits) {
         set_err("%d local nodes and paths of up to %d steps exceed the LDS budget of the scan kernels",
                 s->n_local, (int)max_path_len);
@@ -3841,7 +3894,7 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
             a2.L = L;
             a2.lids = s->d_lids;
             a2.n_paths = n_paths;
-            int tile = (int)std::min<size_t>(((size_t)LDS_BUDGET - scan2_fixed) / scan2_per_path, TILE2_MAX);
+            int tile = nm8 ? tile8 : tile32;
             tile = std::max(1, std::min(tile, (int)n_paths));
             a2.tile = tile;
             a2.n_tiles = (n_paths + tile - 1) / tile;
@@ -3878,10 +3931,13 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
                     y_total += seg_chunks(sg.item_hi - sg.item_lo, a2.chunk_mult, a2.chunk_inv_min);
                 }
                 const unsigned grid2 = (unsigned)a2.n_tiles * y_total;
-                if (s->d_item_weight)
-                    hipLaunchKernelGGL(k_scan2<true>, dim3(grid2), dim3(SCAN_THREADS), lds2, st, a2);
-                else
-                    hipLaunchKernelGGL(k_scan2<false>, dim3(grid2), dim3(SCAN_THREADS), lds2, st, a2);
+                if (s->d_item_weight) {
+                    if (nm8) hipLaunchKernelGGL((k_scan2<true, true>), dim3(grid2), dim3(SCAN_THREADS), lds2, st, a2);
+                    else hipLaunchKernelGGL((k_scan2<true, false>), dim3(grid2), dim3(SCAN_THREADS), lds2, st, a2);
+                } else {
+                    if (nm8) hipLaunchKernelGGL((k_scan2<false, true>), dim3(grid2), dim3(SCAN_THREADS), lds2, st, a2);
+                    else hipLaunchKernelGGL((k_scan2<false, false>), dim3(grid2), dim3(SCAN_THREADS), lds2, st, a2);
+                }
                 HIP_TRY(hipGetLastError());
                 s->last_grid += (int)grid2;
             }

@@ -1,0 +1,189 @@
+"""GPU parity of the two scan kernels.
+
+k_scan   walks occurrence chains per (item, tile path); it keeps the rare
+         alignment lengths and the batches of a few dozen paths.
+k_scan2  answers the subpath test for all tile paths at once from a hashed
+         window table per (tile, alignment length).
+
+`GFAL_SCAN=1` / `=2` force one kernel for everything, `GFAL_HASH_MIN_ITEMS=1`
+makes every length a k_scan2 segment in the automatic mode; every case below is
+compared bit for bit with the oracle (reference src/eval.cpp:67-108 restated)
+under each of them.  The reference has no fixture for this path beyond
+tests/golden (parity unpinned): the oracle is the checker.
+"""
+import random
+
+import numpy as np
+import pytest
+
+import oracle
+from gfalign_amd.scorer import GFAL_STEP_OTHER, Scorer
+from helpers import csr, random_case, walk_case
+
+pytestmark = pytest.mark.gpu
+
+MODES = [{"GFAL_SCAN": "1"}, {"GFAL_SCAN": "2"}, {"GFAL_HASH_MIN_ITEMS": "1"}, {}]
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    from gfalign_amd import scorer
+    if scorer.device_count() < 1:
+        pytest.fail("these tests need an MI355X: the product path has no CPU fallback")
+
+
+def check_modes(monkeypatch, alns, paths, n_nodes, filters=(True, False), **kw):
+    aoff, ast = csr(alns)
+    poff, pst = csr(paths)
+    exp = {f: oracle.evaluate_paths(aoff, ast, poff, pst, f) for f in filters}
+    infos = []
+    for env in MODES:
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with Scorer(aoff, ast, n_nodes, **kw) as sc:
+            for f in filters:
+                got = sc.evaluate_paths(poff, pst, f)
+                for name, g, e in zip(("bad", "good", "unaligned"), got, exp[f]):
+                    assert np.array_equal(g, e), (env, f, name, np.flatnonzero(g != e)[:8])
+            infos.append(sc.info())
+        for k in env:
+            monkeypatch.delenv(k)
+    return infos
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_every_length_in_both_kernels(gpu, monkeypatch, seed):
+    """Alignments of 1..40 steps cut from one walk (exact-length code up to 12
+    steps, pair-count code up to 33, run-time loops beyond), 120 paths: enough
+    for k_scan2 in the automatic mode."""
+    rnd = random.Random(seed)
+    alns, paths = walk_case(rnd, 30, 160, 5000, 120, 40)
+    check_modes(monkeypatch, alns, paths, 32)
+
+
+def test_tiny_alphabet_overhangs(gpu, monkeypatch):
+    """Two to three nodes: repeats everywhere, so the table holds few distinct
+    windows with many duplicates, nearly every alignment touches the paths'
+    first node (the triage runs for most lanes) and many pairs reach the DP."""
+    rnd = random.Random(21)
+    alns, paths = random_case(rnd, 3, 4000, 130, 9, 30, min_m=1, min_n=2)
+    infos = check_modes(monkeypatch, alns, paths, 4)
+    assert all(i["dp_pairs"] > 1000 for i in infos)
+
+
+def test_unrelated_long_paths_take_several_passes(gpu, monkeypatch):
+    """Eight unrelated 1000-step paths have ~16 000 distinct windows per length:
+    more than one table holds (4096), so a workgroup rebuilds the table and
+    passes over its items again for the rest of the tile's paths."""
+    rnd = random.Random(31)
+    n_nodes = 600
+    paths = [[(rnd.randrange(n_nodes) << 1) | rnd.randrange(2) for _ in range(rnd.randint(940, 1000))]
+             for _ in range(100)]
+    alns = []
+    for _ in range(6000):
+        p = paths[rnd.randrange(len(paths))]
+        m = rnd.randint(1, 9)
+        s = rnd.randrange(0, len(p) - m)
+        b = list(p[s:s + m])
+        if rnd.random() < 0.2:
+            b[rnd.randrange(m)] = (rnd.randrange(n_nodes) << 1) | rnd.randrange(2)
+        if rnd.random() < 0.5:
+            b = [x ^ 1 for x in reversed(b)]
+        alns.append(b)
+    check_modes(monkeypatch, alns, paths, n_nodes, filters=(True,))
+
+
+def test_siblings_and_prefixes_share_their_windows(gpu, monkeypatch):
+    """What a search submits: extensions of one parent (all steps but the last
+    shared), prefixes of one walk, and walks that differ in one early step --
+    the base path of a tile enters the shared windows for all of them."""
+    rnd = random.Random(41)
+    n_nodes = 40
+    walk = [(rnd.randrange(n_nodes) << 1) | rnd.randrange(2) for _ in range(400)]
+    paths = []
+    for k in range(60):                                   # siblings
+        paths.append(walk[:200] + [(rnd.randrange(n_nodes) << 1) | rnd.randrange(2)])
+    for k in range(40):                                   # prefixes
+        paths.append(walk[:rnd.randint(2, 400)])
+    for k in range(40):                                   # one early substitution
+        p = list(walk[:rnd.randint(150, 400)])
+        p[rnd.randrange(0, 20)] = (rnd.randrange(n_nodes) << 1) | rnd.randrange(2)
+        paths.append(p)
+    alns = []
+    for _ in range(8000):
+        m = rnd.randint(1, 14)
+        s = rnd.randrange(0, 400 - m)
+        b = list(walk[s:s + m])
+        if rnd.random() < 0.15:
+            b[rnd.randrange(m)] = (rnd.randrange(n_nodes) << 1) | rnd.randrange(2)
+        if rnd.random() < 0.5:
+            b = [x ^ 1 for x in reversed(b)]
+        alns.append(b)
+    check_modes(monkeypatch, alns, paths, n_nodes)
+
+
+def test_tiles_whose_paths_start_differently(gpu, monkeypatch):
+    """The triage's shortcut (only alignments on the tile's first node can
+    overhang) needs one first step per tile; tiles without one take the exact
+    test for every open lane.  Also a first step of neither orientation
+    (GFAL_STEP_OTHER: the search's source before its first extension)."""
+    rnd = random.Random(51)
+    alns, paths = random_case(rnd, 6, 5000, 128, 7, 24, min_m=1, min_n=2)
+    for k in range(0, len(paths), 5):
+        paths[k][0] = GFAL_STEP_OTHER | (paths[k][0] & ~1)
+    check_modes(monkeypatch, alns, paths, 8)
+
+
+def test_dedup_and_shards_through_k_scan2(gpu, monkeypatch):
+    """Weighted lanes (gfal_scorer_create_dedup) and a 3-way sharded set give
+    the counters of the plain scorer under k_scan2 as well."""
+    rnd = random.Random(61)
+    alns, paths = walk_case(rnd, 20, 100, 6000, 110, 10)
+    alns = alns + alns[:2000] + alns[:500]                 # copies: weights up to 3
+    aoff, ast = csr(alns)
+    poff, pst = csr(paths)
+    exp = oracle.evaluate_paths(aoff, ast, poff, pst, True)
+    monkeypatch.setenv("GFAL_SCAN", "2")
+    with Scorer(aoff, ast, 32, dedup=True) as sc:
+        got = sc.evaluate_paths(poff, pst, True)
+        assert sc.info()["n_lanes"] < len(alns)
+    for g, e in zip(got, exp):
+        assert np.array_equal(g, e)
+    acc = [np.zeros(len(paths), np.uint64) for _ in range(3)]
+    for k in range(3):
+        with Scorer(aoff, ast, 32, shard=(k, 3)) as sc:
+            for a, part in zip(acc, sc.evaluate_paths(poff, pst, True)):
+                a += part
+    for a, e in zip(acc, exp):
+        assert np.array_equal(a, e.astype(np.uint64))
+
+
+def test_many_nodes_need_no_chain_images(gpu):
+    """15 000 nodes: k_scan's path images (a first-occurrence table per node) no
+    longer fit the LDS; k_scan2 only keeps node masks per node and takes every
+    length.  (Round 1 answered GFAL_E_RANGE above ~11 000 nodes; the reference
+    has no limit, include/nodetable.h:11-43.)"""
+    rnd = random.Random(71)
+    n_nodes = 15000
+    walk = [(v << 1) | rnd.randrange(2) for v in rnd.sample(range(n_nodes), n_nodes)]
+    paths = [walk[s:s + rnd.randint(50, 600)] for s in (rnd.randrange(0, n_nodes - 600) for _ in range(100))]
+    alns = []
+    for _ in range(4000):
+        m = rnd.randint(1, 12)
+        s = rnd.randrange(0, n_nodes - m)
+        b = list(walk[s:s + m])
+        if rnd.random() < 0.5:
+            b = [x ^ 1 for x in reversed(b)]
+        alns.append(b)
+    # make sure every node occurs in some alignment (all of them become local nodes)
+    for s in range(0, n_nodes - 8, 8):
+        alns.append(walk[s:s + 8])
+    aoff, ast = csr(alns)
+    poff, pst = csr(paths)
+    with Scorer(aoff, ast, n_nodes) as sc:
+        assert sc.info()["n_local_nodes"] >= 14000
+        got = sc.evaluate_paths(poff, pst, True)
+        few = sc.evaluate_paths(poff[:9], pst[:poff[8]], True)     # a small batch as well
+    exp = oracle.evaluate_paths(aoff, ast, poff, pst, True)
+    for g, f, e in zip(got, few, exp):
+        assert np.array_equal(g, e) and np.array_equal(f, e[:8])
