@@ -11,8 +11,8 @@ per GPU): the alignments are sharded over the ranks, every rank scores the whole
 batch against its shard, and the per-path counters are summed with one RCCL
 all-reduce inside the step -- the same total work for every N ("strong").
 
-Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for how `roofline`
-and `cpu_baseline` are defined.
+Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for how `roofline`,
+`cpu_baseline` and `search_mode` are defined.
 """
 import argparse
 import json
@@ -26,6 +26,103 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def _load_json(name):
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f)
+
+
+def search_mode(t, device):
+    """The metric is paths scored per second IN SEARCH MODE: what `gfalign search`
+    itself submits, through the blocking C ABI (host buffers in, counters out).
+    Runs the CLI once on the workload's tangle (-m 20000, default speculation),
+    then replays the candidate batches it scored:
+      first_10k / deep_10k  the first 10 000 candidates and candidates 50 001..60 000
+                            of the search as one batch each,
+      stream                every batch of the search in order, one blocking call each
+                            (the search's own call pattern without its host work),
+      cli                   the search itself: scored candidates / search-loop seconds.
+    """
+    import re
+    import subprocess
+    import tempfile
+    from gfalign_amd import build
+    from gfalign_amd.scorer import Scorer
+    out = {}
+    with tempfile.TemporaryDirectory(prefix="gfalign_bench_") as d:
+        t.write_gfa(d + "/g.gfa")
+        t.write_nodelist(d + "/nodes.tsv")
+        t.write_gaf(d + "/a.gaf")
+        cli = build.build_cli()
+        dump = d + "/batches.bin"
+        t0 = time.perf_counter()
+        p = subprocess.run([cli, "search", "-f", d + "/g.gfa", "-g", d + "/a.gaf", "-n", d + "/nodes.tsv",
+                            "-s", "utig4-0", "-d", "utig4-%d" % (t.V - 1), "-m", "20000", "--verbose",
+                            "--device", str(device)],
+                           env=dict(os.environ, GFALIGN_DUMP_BATCHES=dump), capture_output=True, text=True)
+        wall = time.perf_counter() - t0
+        if p.returncode != 0:
+            return {"error": "gfalign search failed: " + p.stderr[-300:]}
+        m1 = re.search(r"search ([0-9.]+) s \(candidates ([0-9.]+) s, scoring ([0-9.]+) s\)", p.stderr)
+        m2 = re.search(r"scored (\d+) candidate paths in (\d+) batches", p.stderr)
+        if m1 and m2:
+            scored, nb = int(m2.group(1)), int(m2.group(2))
+            out["cli"] = {"command": "gfalign search -m 20000 (default speculation; GAF parse and scorer "
+                                     "creation not counted)",
+                          "scored_paths": scored, "batches": nb, "search_loop_s": float(m1.group(1)),
+                          "scoring_s": float(m1.group(3)), "process_wall_s": wall,
+                          "paths_per_s": scored / float(m1.group(1))}
+        raw = np.fromfile(dump, dtype=np.int32)
+    batches, at = [], 0
+    while at < len(raw):
+        P, S = int(raw[at]), int(raw[at + 1])
+        batches.append((raw[at + 2: at + 3 + P].copy(), raw[at + 3 + P: at + 3 + P + S].copy()))
+        at += 3 + P + S
+
+    def merged(skip, want):
+        offs, steps, total, n, seen = [np.zeros(1, np.int32)], [], 0, 0, 0
+        for off, st in batches:
+            P = len(off) - 1
+            seen += P
+            if seen <= skip or n >= want:
+                continue
+            take = min(P, want - n)
+            offs.append(off[1:take + 1] + total)
+            steps.append(st[:off[take]])
+            total += int(off[take])
+            n += take
+        return np.concatenate(offs).astype(np.int32), np.concatenate(steps).astype(np.int32)
+
+    with Scorer(t.aln_off, t.aln_steps, t.V, device=device) as sc:
+        for name, skip in (("first_10k", 0), ("deep_10k", 50000)):
+            off, st = merged(skip, 10000)
+            if len(off) < 2:
+                continue
+            sc.evaluate_paths(off, st, True)
+            t0 = time.perf_counter()
+            reps = 3
+            for _ in range(reps):
+                sc.evaluate_paths(off, st, True)
+            dt = (time.perf_counter() - t0) / reps
+            out[name] = {"paths": len(off) - 1, "mean_path_len": float(np.diff(off).mean()),
+                         "ms_per_batch": 1e3 * dt, "paths_per_s": (len(off) - 1) / dt}
+        for off, st in batches[:8]:
+            sc.evaluate_paths(off, st, True)
+        t0 = time.perf_counter()
+        n = 0
+        for off, st in batches:
+            sc.evaluate_paths(off, st, True)
+            n += len(off) - 1
+        dt = time.perf_counter() - t0
+        out["stream"] = {"batches": len(batches), "paths": n, "mean_batch": n / max(1, len(batches)),
+                         "ms_per_batch": 1e3 * dt / max(1, len(batches)), "paths_per_s": n / dt}
+    out["note"] = ("blocking gfal_scorer_score (host buffers, PCIe copies and one sync per call included) on "
+                   "the candidate batches gfalign search itself scored on this workload's tangle")
+    return out
 
 
 def cpu_baseline(t, budget_pairs=3.2e6):
@@ -101,6 +198,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="config3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-search-mode", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -189,18 +287,37 @@ def main():
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = P * args.steps / elapsed
-        # dominant kernel: k_scan.  Algorithmic bytes of one launch on this rank
-        # (SURVEY.md 8(d)): sum over candidates of 4 S + 4 (N+1) + 4 n + 12 with
-        # this rank's S and N.
+        # Dominant kernels: the scan (k_scan2, plus k_scan for the rare alignment
+        # lengths), timed live with HIP events on the caller's stream around every
+        # launch of the timed region (gfal_scorer_set_profiling).
+        #
+        # Roofline.  The scan re-uses every alignment load for all paths of a tile
+        # out of LDS and the alignment set lives in L2 / Infinity Cache: it moves
+        # ~0.5 % of its algorithmic bytes through HBM, so HBM bandwidth does not
+        # bound it.  What bounds it is instruction issue on the 1024 SIMDs:
+        #   achieved = VALU wave-instructions of one step (SQ_INSTS_VALU of the scan
+        #              kernels, rocprofv3 PMC pass committed under profiles/) / the
+        #              live scan time,
+        #   peak     = the best sustained VALU issue rate measured on this chip by
+        #              tools/valu_rate.hip (simple 2-operand integer ops; the kernel's
+        #              3-operand / compare / readlane ops issue at ~60 % of that).
+        # The algorithmic-bytes figure of SURVEY.md 8(d) and the physical HBM traffic
+        # stay in the object as `hbm_*` fields.
         S_r, N_r = int(info["n_steps"]), int(info["n_aln"])
         alg_bytes = P * (4 * S_r + 4 * (N_r + 1) + 12) + 4 * total_steps
         scan_s = info["scan_ms"] * 1e-3
-        achieved = alg_bytes / scan_s / 1e9 if scan_s > 0 else None
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
-        if world == 1 and os.path.exists(tpath):
-            with open(tpath) as f:
-                traffic = json.load(f).get("hbm_bytes_per_launch")
+        alg_gbs = alg_bytes / scan_s / 1e9 if scan_s > 0 else None
+        traffic = issue = None
+        peaks = _load_json("issue_peaks.json")
+        if world == 1:
+            tr = _load_json("traffic_%s.json" % args.workload)
+            traffic = tr.get("hbm_bytes_per_launch") if tr else None
+            issue = _load_json("issue_%s.json" % args.workload)
+        achieved = peak = frac = None
+        if issue and peaks and scan_s > 0:
+            achieved = issue["valu_wave_insts_per_step"] / scan_s / 1e9           # G wave-inst/s, whole chip
+            peak = peaks["valu_vop2_ginst_per_s_simd"] * peaks["n_simds"]
+            frac = achieved / peak
         out = {
             "metric": "candidate paths scored/sec in search mode",
             "value": value,
@@ -223,20 +340,28 @@ def main():
                 "dp_pairs_per_step": info["dp_pairs"],
             },
             "roofline": {
-                "bound": "hbm",
-                "kernel": "k_scan",
+                "bound": "valu-issue",
+                "kernel": "k_scan2 (+ k_scan for the rare alignment lengths)",
                 "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+                "peak": peak,
+                "unit": "G wave-instructions/s",
+                "frac": frac,
                 "traffic": traffic,
-                "algorithmic_bytes_per_launch": alg_bytes,
                 "kernel_ms": info["scan_ms"],
                 "dp_kernel_ms": info["dp_ms"],
                 "call_ms": info["total_ms"],
-                "note": "algorithmic bytes re-read the whole alignment set per candidate; "
-                        "k_scan reuses each alignment load for tile_paths candidates from "
-                        "LDS, so achieved may exceed the HBM peak (DESIGN.md)",
+                "valu_wave_insts_per_step": issue["valu_wave_insts_per_step"] if issue else None,
+                "salu_wave_insts_per_step": issue["salu_wave_insts_per_step"] if issue else None,
+                "peak_vop3_class": (peaks["valu_vop3_ginst_per_s_simd"] * peaks["n_simds"]) if peaks else None,
+                "hbm_algorithmic_bytes_per_launch": alg_bytes,
+                "hbm_algorithmic_gbs": alg_gbs,
+                "hbm_algorithmic_frac_of_8tbs": (alg_gbs / HBM_PEAK_GBS) if alg_gbs else None,
+                "hbm_physical_gbs": (traffic / scan_s / 1e9) if traffic and scan_s > 0 else None,
+                "note": "not HBM-bound: the scan moves ~0.5 % of its algorithmic bytes (SURVEY.md 8(d): the "
+                        "alignment set re-read per candidate) through HBM -- tiles of candidate paths share "
+                        "each load from LDS, the set sits in L2 / Infinity Cache -- so the algorithmic rate "
+                        "exceeds the HBM peak and says nothing about the binding unit, which is SIMD "
+                        "instruction issue; counters and measured peaks: profiles/ (DESIGN.md section 5)",
             },
         }
         out["config"]["counter_checksum"] = int(bad.astype(np.uint64).sum() * 3 +
@@ -281,6 +406,8 @@ def main():
                                 "note": "gfal_scorer_create_dedup: identical alignments collapsed into "
                                         "weighted lanes, same counters; reported separately"}
             out["config"]["parity_sample"] += " and vs oracle/gfalign_fast.c on 64 paths x all alignments"
+        if world == 1 and not args.no_search_mode:
+            out["search_mode"] = search_mode(t, local_rank)
         print(json.dumps(out))
     sc.close()
     if world > 1:

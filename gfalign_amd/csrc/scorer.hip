@@ -3915,7 +3915,13 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
             int y_want = (want_groups + a2.n_tiles - 1) / a2.n_tiles;
             int min_items = 100 * SCAN_WAVES;
             if (a2.n_tiles < slots) {          // fewer tiles than resident workgroups: fill the GPU
-                y_want = std::min(y_want, (4 * slots + a2.n_tiles - 1) / a2.n_tiles);
+                // quarter rounds of the resident workgroups to aim for: every workgroup
+                // pays a prologue, so a search-sized batch (128 paths: 16 tiles) wants
+                // ONE round (scan 0.14 ms against 0.24 ms with four), a few hundred
+                // paths two (scripts/small_batch_probe.py)
+                int rounds4 = a2.n_tiles <= 40 ? 4 : 8;
+                if (const char *env = getenv("GFAL_SCAN2_ROUNDS4")) rounds4 = std::max(1, atoi(env));
+                y_want = std::min(y_want, (rounds4 * slots / 4 + a2.n_tiles - 1) / a2.n_tiles);
                 min_items = 12 * SCAN_WAVES;
             }
             a2.chunk_mult = (((unsigned long long)y_want << 24) + (unsigned long long)items2 - 1) /

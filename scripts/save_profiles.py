@@ -1,10 +1,18 @@
 """Condense gpurun_out/prof_<tag>_* (scripts/collect_profiles.sh) into profiles/."""
 import collections, csv, glob, json, os, shutil, sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-KEYS = ("k_scan", "k_dp_regs<4", "k_dp_regs<8", "k_dp_regs<16", "k_dp_regs<32", "k_dp_long", "k_dp_sys",
-        "k_len_sort_block", "k_prep",
-        "k_wl_scatter", "k_wl_offsets", "read_u16", "read_b128")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+# longest key first: "k_scan2" before "k_scan"
+KEYS = ("k_scan2", "k_scan", "k_dp_regs<4", "k_dp_regs<8", "k_dp_regs<16", "k_dp_regs<32", "k_dp_long",
+        "k_dp_sys", "k_len_sort_block", "k_prep", "k_wl_scatter", "k_wl_offsets", "k_unpermute",
+        "read_u16", "read_b128")
+
+
+def kernel_key(name):
+    for k in KEYS:
+        if k in name:
+            return k
+    return None
 
 
 def summ(d):
@@ -14,11 +22,8 @@ def summ(d):
     for f in files:
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
-            n = r["Kernel_Name"]
-            for k in KEYS:
-                if k in n:
-                    n = k
-            if n in KEYS:
+            n = kernel_key(r["Kernel_Name"])
+            if n:
                 acc[n][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for n, c in acc.items():
             out[n] = {k: {"mean_per_dispatch": sum(v) / len(v), "dispatches": len(v)}
@@ -31,8 +36,8 @@ stats = sorted(glob.glob("gpurun_out/prof_%s_stats/*/*_kernel_stats.csv" % tag),
 shutil.copy(stats, "profiles/%s_bench_config3_kernel_stats.csv" % tag)
 pmc = {
     "_how": "scripts/collect_profiles.sh: one rocprofv3 --kernel-trace --pmc pass per counter "
-            "group over `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline` (cd /tmp; "
-            "TMPDIR=/tmp); means per kernel dispatch, 1x MI355X, workload config3",
+            "group over `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-search-mode` "
+            "(cd /tmp; TMPDIR=/tmp); means per kernel dispatch, 1x MI355X, workload config3",
     "calibration (tools/fetch_calib, 1 GiB streamed once per kernel)": {
         **summ("calib"),
         "note": "FETCH_SIZE is in KiB and reads 1/2 of the bytes for 2 B/lane and 16 B/lane "
@@ -41,10 +46,20 @@ pmc = {
     "SQ_1": summ("sq1"), "SQ_2": summ("sq2"), "GRBM": summ("grbm"),
 }
 json.dump(pmc, open("profiles/%s_pmc_config3.json" % tag, "w"), indent=1)
-fetch = pmc["FETCH_SIZE"]["k_scan"]["FETCH_SIZE"]["mean_per_dispatch"]
-write = pmc["WRITE_SIZE"]["k_scan"]["WRITE_SIZE"]["mean_per_dispatch"]
+
+
+def per_step(group, counter):
+    """sum over the two scan kernels of one bench step (each is launched once per step)"""
+    tot = 0.0
+    for k in ("k_scan2", "k_scan"):
+        tot += pmc[group].get(k, {}).get(counter, {}).get("mean_per_dispatch", 0.0)
+    return tot
+
+
+fetch, write = per_step("FETCH_SIZE", "FETCH_SIZE"), per_step("WRITE_SIZE", "WRITE_SIZE")
 traffic = {
-    "workload": "config3", "kernel": "k_scan", "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write,
+    "workload": "config3", "kernels": "k_scan2 + k_scan (one launch each per step)",
+    "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write,
     "hbm_bytes_per_launch": int(fetch * 1024 * 2 + write * 1024),
     "method": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over bench.py; read side "
               "doubled (gfx950 correction, confirmed by tools/fetch_calib for this kernel's access "
@@ -52,6 +67,39 @@ traffic = {
               "this is an upper bound on HBM bytes",
     "source": "profiles/%s_pmc_config3.json" % tag}
 json.dump(traffic, open("profiles/traffic_config3.json", "w"), indent=1)
+issue = {
+    "workload": "config3", "kernels": "k_scan2 + k_scan (one launch each per step)",
+    "valu_wave_insts_per_step": per_step("SQ_1", "SQ_INSTS_VALU"),
+    "salu_wave_insts_per_step": per_step("SQ_1", "SQ_INSTS_SALU"),
+    "lds_wave_insts_per_step": per_step("SQ_1", "SQ_INSTS_LDS"),
+    "vmem_rd_wave_insts_per_step": per_step("SQ_1", "SQ_INSTS_VMEM_RD"),
+    "wave_quad_cycles_per_step": per_step("SQ_1", "SQ_WAVE_CYCLES"),
+    "wait_any_quad_cycles_per_step": per_step("SQ_2", "SQ_WAIT_ANY"),
+    "source": "profiles/%s_pmc_config3.json (SQ_INSTS_* count wave-instructions)" % tag}
+json.dump(issue, open("profiles/issue_config3.json", "w"), indent=1)
+
+# measured issue peaks (tools/valu_rate.hip)
+vr = "gpurun_out/valu_rate_%s.jsonl" % tag
+if os.path.exists(vr):
+    shutil.copy(vr, "profiles/%s_valu_rate.jsonl" % tag)
+    rows = [json.loads(l) for l in open(vr) if l.strip()]
+
+    def best(kind, key):
+        return max(r[key] for r in rows if r["kind"] == kind and key in r)
+    peaks = {
+        "n_simds": 1024, "n_cus": 256,
+        "valu_vop2_ginst_per_s_simd": max(best("v_and_b32", "valu_ginst_per_s_simd"),
+                                          best("v_add_u32", "valu_ginst_per_s_simd")),
+        "valu_vop3_ginst_per_s_simd": max(best("v_alignbit_b32", "valu_ginst_per_s_simd"),
+                                          best("v_bfe_u32", "valu_ginst_per_s_simd"),
+                                          best("v_cmp_eq_u32->sgpr", "valu_ginst_per_s_simd")),
+        "valu_scan_mix_ginst_per_s_simd": best("mix scan(4v:2s:ds/8)", "valu_ginst_per_s_simd"),
+        "salu_ginst_per_s_cu": best("salu(and_b64,bcnt1,add)", "salu_ginst_per_s_cu"),
+        "lds_b32_ginst_per_s_cu": best("ds_read_b32 x8", "lds_ginst_per_s_cu"),
+        "source": "profiles/%s_valu_rate.jsonl (tools/valu_rate.hip: best sustained rate over 1..8 "
+                  "waves per SIMD, wave-instructions per second over the span of the launch)" % tag}
+    json.dump(peaks, open("profiles/issue_peaks.json", "w"), indent=1)
+    print(json.dumps(peaks, indent=1))
 if os.path.exists("gpurun_out/workloads_%s.txt" % tag):
     shutil.copy("gpurun_out/workloads_%s.txt" % tag, "profiles/%s_workloads.txt" % tag)
 try:
@@ -61,7 +109,8 @@ try:
 except Exception as e:
     print("no bench json:", e)
 print(json.dumps(traffic, indent=1))
+print(json.dumps(issue, indent=1))
 for r in csv.DictReader(open(stats)):
-    for k in KEYS:
-        if k in r["Name"]:
-            print("%-14s calls %3s avg %9.1f us" % (k, r["Calls"], float(r["AverageNs"]) / 1e3))
+    k = kernel_key(r["Name"])
+    if k:
+        print("%-14s calls %3s avg %9.1f us" % (k, r["Calls"], float(r["AverageNs"]) / 1e3))

@@ -14,10 +14,9 @@
 // exactly what is written), stamps s_memtime before and after, and stores the
 // difference.  Exactly W blocks of 256 threads (1 wave per SIMD each) are made
 // resident per CU by giving each block 160 KiB / W of LDS; grid = CUs x W.
-// Output (JSON lines): per instruction kind and W,
-//   cyc_per_inst_simd = (median wave cycles) / (instructions per wave x W)
-// i.e. the cycles one SIMD needs per wave-instruction with W waves resident;
-// for SALU kinds cyc_per_inst_cu is per scalar unit (4 x W waves share it).
+// Output (JSON lines): per instruction kind and W, the sustained issue rate in
+// G wave-instructions per second per SIMD (VALU) or per CU (SALU, LDS), over the
+// span of the launch, and the same in cycles at the clock the waves measured.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -35,7 +34,7 @@
         }                                                                           \
     } while (0)
 
-constexpr int ITERS = 5000;   // x UNROLL blocks per wave
+constexpr int ITERS = 20000;  // x UNROLL blocks per wave (launch ramp / tail << span)
 constexpr int UNROLL = 4;
 
 // eight independent chains: a..h; s = shift / second operand
@@ -260,14 +259,17 @@ int report(int n_cus)
         if (run<KIND>(n_cus, w, &r)) return 1;
         const double nv = (double)per_block[KIND][0] * ITERS * UNROLL, ns = (double)per_block[KIND][1] * ITERS * UNROLL,
                      nl = (double)per_block[KIND][2] * ITERS * UNROLL;
-        // rates in wall time (G wave-instructions per second): the chip lowers its
-        // clock under an all-SIMD VALU load, so cycles alone mislead
+        // Rates over the SPAN of the launch (first wave start .. last wave end, 100 MHz
+        // wall clock): all instructions of a SIMD's W waves divided by the time the
+        // SIMD needed for them.  (Per-wave durations mislead: the arbiter favours the
+        // oldest waves, which then finish early and leave the rest of the span to the
+        // others.)  G wave-instructions per second; cycles at the measured clock.
+        const double clock = r.cycles / r.dur_ns;
         printf("{\"kind\": \"%s\", \"waves_per_simd\": %d, \"resident_waves_per_simd\": %.2f, "
-               "\"wave_ns\": %.0f, \"clock_ghz\": %.3f", kind_name[KIND], w, r.concurrency, r.dur_ns,
-               r.cycles / r.dur_ns);
-        if (nv > 0) printf(", \"valu_ginst_per_s_simd\": %.4f, \"cyc_per_valu_simd\": %.3f", nv * w / r.dur_ns, r.cycles / (nv * w));
-        if (ns > 0) printf(", \"salu_ginst_per_s_cu\": %.4f, \"cyc_per_salu_cu\": %.3f", ns * w * 4 / r.dur_ns, r.cycles / (ns * w * 4));
-        if (nl > 0) printf(", \"lds_ginst_per_s_cu\": %.4f, \"cyc_per_lds_cu\": %.3f", nl * w * 4 / r.dur_ns, r.cycles / (nl * w * 4));
+               "\"span_us\": %.1f, \"clock_ghz\": %.3f", kind_name[KIND], w, r.concurrency, r.span_ns / 1e3, clock);
+        if (nv > 0) printf(", \"valu_ginst_per_s_simd\": %.4f, \"cyc_per_valu_simd\": %.3f", nv * w / r.span_ns, r.span_ns * clock / (nv * w));
+        if (ns > 0) printf(", \"salu_ginst_per_s_cu\": %.4f, \"cyc_per_salu_cu\": %.3f", ns * w * 4 / r.span_ns, r.span_ns * clock / (ns * w * 4));
+        if (nl > 0) printf(", \"lds_ginst_per_s_cu\": %.4f, \"cyc_per_lds_cu\": %.3f", nl * w * 4 / r.span_ns, r.span_ns * clock / (nl * w * 4));
         printf("}\n");
     }
     return 0;
