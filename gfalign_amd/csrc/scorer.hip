@@ -3095,7 +3095,8 @@ int gfal_scorer_create_ex(const int32_t *aln_off, const int32_t *aln_steps,
 
 static int create_impl(const int32_t *aln_off, const int32_t *aln_steps, int64_t n_aln,
                        int32_t n_nodes, int device, const int32_t *universe, int32_t n_universe,
-                       int32_t shard_index, int32_t n_shards, bool dedup, gfal_scorer **out);
+                       int32_t shard_index, int32_t n_shards, bool dedup, gfal_scorer **out,
+                       uint8_t *plan_owned = nullptr);
 
 int gfal_scorer_create_sharded(const int32_t *aln_off, const int32_t *aln_steps,
                                int64_t n_aln, int32_t n_nodes, int device,
@@ -3119,12 +3120,15 @@ int gfal_scorer_create_dedup(const int32_t *aln_off, const int32_t *aln_steps,
     });
 }
 
+// plan_owned != NULL: the host half only -- which of the alignments this shard
+// would take ([n_aln] flags), no device touched, *out untouched (gfal_shard_owner).
 static int create_impl(const int32_t *aln_off, const int32_t *aln_steps, int64_t n_aln,
                        int32_t n_nodes, int device, const int32_t *universe, int32_t n_universe,
-                       int32_t shard_index, int32_t n_shards, bool dedup, gfal_scorer **out)
+                       int32_t shard_index, int32_t n_shards, bool dedup, gfal_scorer **out,
+                       uint8_t *plan_owned)
 {
-    if (!out) return GFAL_E_ARG;
-    *out = nullptr;
+    if (!out && !plan_owned) return GFAL_E_ARG;
+    if (out) *out = nullptr;
     // GFAL_DEBUG_TIMING=1: where the host side of create spends its time (stderr)
     const bool timing = getenv("GFAL_DEBUG_TIMING") != nullptr;
     auto t_prev = std::chrono::steady_clock::now();
@@ -3143,10 +3147,12 @@ static int create_impl(const int32_t *aln_off, const int32_t *aln_steps, int64_t
     const int64_t S = n_aln ? aln_off[n_aln] : 0;
     if (S < 0 || (S > 0 && !aln_steps)) return GFAL_E_ARG;
 
-    int ndev = gfal_device_count();
-    if (ndev <= 0 || device < 0 || device >= ndev) {
-        if (ndev >= 0) set_err("device %d requested, %d visible", device, ndev);
-        return GFAL_E_NO_DEVICE;
+    if (!plan_owned) {
+        int ndev = gfal_device_count();
+        if (ndev <= 0 || device < 0 || device >= ndev) {
+            if (ndev >= 0) set_err("device %d requested, %d visible", device, ndev);
+            return GFAL_E_NO_DEVICE;
+        }
     }
 
     // ---- validate, find the nodes that occur, bucket by length ----
@@ -3422,9 +3428,10 @@ static int create_impl(const int32_t *aln_off, const int32_t *aln_steps, int64_t
     int64_t own_aln = n_empty, own_steps = 0, n_lanes = 0;
     // Item order: the well-populated lengths first (k_scan2 builds one window
     // table per tile and length, which pays from a few dozen items up), then the
-    // rare ones (k_scan).  The shards of one set agree on the order (same input),
-    // and every length deals its own items round robin, so a shard's segment of a
-    // length holds 1/n of that length's items.
+    // rare ones (k_scan).  The shards of one set agree on the order (same input);
+    // the groups of 64 are dealt round robin in that order (one counter across the
+    // lengths: a counter per length would hand the first shards one group more of
+    // every length), so a shard's segment of a length holds 1/n of its items.
     int hash_min_items = 48;
     if (const char *env = getenv("GFAL_HASH_MIN_ITEMS")) hash_min_items = std::max(1, atoi(env));
     std::vector<int> len_order;
@@ -3438,9 +3445,9 @@ static int create_impl(const int32_t *aln_off, const int32_t *aln_steps, int64_t
         if (!is_hash_len[(size_t)m] && !by_len[(size_t)m].empty()) len_order.push_back(m);
     std::vector<LenSeg> segs;      // one per length, in item order
     int n_hash_items = 0, n_hash_segs = 0;
+    uint64_t global_item = 0;
     for (int m : len_order) {
         const std::vector<int32_t> &idx = by_len[(size_t)m];
-        uint64_t global_item = 0;      // of this length
         const size_t seg_lo = src.size();
         for (size_t at = 0; at < idx.size(); at += WAVE) {
             const size_t cnt = std::min<size_t>(WAVE, idx.size() - at);
@@ -3571,6 +3578,18 @@ static int create_impl(const int32_t *aln_off, const int32_t *aln_steps, int64_t
             for (size_t v = 0; v < h.size(); ++v) hist[v] += h[v];
     }
     mark("items");
+    if (plan_owned) {
+        memset(plan_owned, 0, (size_t)n_aln);
+        for (int32_t orig : slot_orig)
+            if (orig >= 0) plan_owned[(size_t)orig] = 1;
+        if (shard_index == 0)
+            for (int64_t k = 0; k < n_aln; ++k)
+                if (aln_off[k + 1] == aln_off[k]) plan_owned[(size_t)k] = 1;
+        if (dedup)
+            for (int64_t k = 0; k < n_aln; ++k)
+                if (plan_owned[(size_t)rep_of[(size_t)k]]) plan_owned[(size_t)k] = 1;
+        return GFAL_OK;
+    }
 
     gfal_scorer *s = new (std::nothrow) gfal_scorer();
     if (!s) return GFAL_E_NOMEM;
@@ -3691,6 +3710,31 @@ static int create_impl(const int32_t *aln_off, const int32_t *aln_steps, int64_t
 }
 
 void gfal_scorer_destroy(gfal_scorer *s) { free_scorer(s); }
+
+int gfal_shard_owner(const int32_t *aln_off, const int32_t *aln_steps, int64_t n_aln,
+                     int32_t n_nodes, const int32_t *universe, int32_t n_universe,
+                     int32_t n_shards, int32_t *owner)
+{
+    if (!owner || n_shards < 1) return GFAL_E_ARG;
+    return no_throw([&] {
+        std::vector<uint8_t> flags((size_t)std::max<int64_t>(n_aln, 1));
+        for (int64_t k = 0; k < n_aln; ++k) owner[k] = -1;
+        for (int32_t sh = 0; sh < n_shards; ++sh) {
+            const int rc = create_impl(aln_off, aln_steps, n_aln, n_nodes, 0, universe, n_universe, sh,
+                                       n_shards, false, nullptr, flags.data());
+            if (rc != GFAL_OK) return rc;
+            for (int64_t k = 0; k < n_aln; ++k)
+                if (flags[(size_t)k]) {
+                    if (owner[k] >= 0) {
+                        set_err("alignment %lld is claimed by shards %d and %d", (long long)k, owner[k], sh);
+                        return GFAL_E_ARG;
+                    }
+                    owner[k] = sh;
+                }
+        }
+        return GFAL_OK;
+    });
+}
 
 int gfal_scorer_set_profiling(gfal_scorer *s, int enable)
 {

@@ -49,6 +49,8 @@ EXPORTS = {
     "gfal_scorer_create_ex": (ctypes.c_int, [_i32p, _i32p, ctypes.c_int64, ctypes.c_int32,
                                              ctypes.c_int, _i32p, ctypes.c_int32,
                                              ctypes.POINTER(ctypes.c_void_p)]),
+    "gfal_shard_owner": (ctypes.c_int, [_i32p, _i32p, ctypes.c_int64, ctypes.c_int32, _i32p,
+                                        ctypes.c_int32, ctypes.c_int32, _i32p]),
     "gfal_scorer_destroy": (None, [ctypes.c_void_p]),
     "gfal_scorer_score": (ctypes.c_int, [ctypes.c_void_p, _i32p, _i32p, ctypes.c_int32,
                                          ctypes.c_int, _u32p, _u32p, _u32p]),
@@ -109,6 +111,21 @@ def _i32(a):
 
 def _ptr(a, ty):
     return a.ctypes.data_as(ctypes.POINTER(ty))
+
+
+def shard_owner(aln_off, aln_steps, n_nodes, n_shards, universe=None):
+    """owner[k] = the shard of gfal_scorer_create_sharded that takes alignment k
+    (host code of the library: works without a GPU)."""
+    lib = load_library()
+    aln_off, aln_steps = _i32(aln_off), _i32(aln_steps)
+    n = len(aln_off) - 1
+    owner = np.zeros(max(n, 1), np.int32)
+    uni = None if universe is None else _i32(universe)
+    _check(lib.gfal_shard_owner(_ptr(aln_off, ctypes.c_int32), _ptr(aln_steps, ctypes.c_int32), n,
+                                int(n_nodes), None if uni is None else _ptr(uni, ctypes.c_int32),
+                                0 if uni is None else len(uni), int(n_shards),
+                                _ptr(owner, ctypes.c_int32)))
+    return owner[:n]
 
 
 def pack_step(node_id, orientation):

@@ -1,12 +1,20 @@
 """Alignment sharding for the multi-GPU path.
 
 evaluatePath's counters are sums over alignments of independent per-pair
-decisions (reference src/eval.cpp:80-106), so the alignment set is cut into
-contiguous ranges with equal step counts, one per rank; every rank scores the
-whole candidate batch against its range and the per-path counters are summed
+decisions (reference src/eval.cpp:80-106): every rank scores the whole candidate
+batch against its shard of the alignments and the per-path counters are summed
 with ONE integer all-reduce (RCCL over xGMI on the GPU box, gloo in the CPU
 tests).  Integer sums are order-independent, so the result is bit-exact for any
-number of ranks.
+number of ranks and any partition.
+
+The partition the PRODUCT uses (bench.py, the CLI) is made inside the scorer:
+every rank hands gfal_scorer_create_sharded the whole set, the library sorts it
+the way the kernels want it (length buckets, content order) and keeps every
+n-th group of 64 -- policy "product" here asks the library for exactly that
+assignment (gfal_shard_owner, host code, no GPU needed).  "range" (contiguous
+ranges balanced by step count) and "content" (copies of one alignment kept
+together) are earlier policies kept for comparison: correct, but slower on the
+GPU.
 """
 import numpy as np
 
@@ -56,26 +64,40 @@ def content_owner(aln_off, aln_steps, world_size):
     return group_owner[inverse]
 
 
-def take_shard(aln_off, aln_steps, rank, world_size, policy="content"):
+def product_owner(aln_off, aln_steps, n_nodes, world_size):
+    """Rank of every alignment under the product's own partition (the library's
+    gfal_shard_owner: what gfal_scorer_create_sharded keeps on each rank)."""
+    from . import scorer
+    return scorer.shard_owner(aln_off, aln_steps, n_nodes, world_size)
+
+
+def take_shard(aln_off, aln_steps, rank, world_size, policy="content", n_nodes=None):
     """CSR arrays of this rank's alignments (offsets re-based to 0).
 
-    policy "content" (default): alignments are dealt to ranks by a hash of their
-    steps (see content_owner); "range": contiguous ranges balanced by step
-    count (shard_bounds).  Any partition gives the same summed counters.
+    policy "product": what gfal_scorer_create_sharded keeps on this rank (needs
+    n_nodes); "content": alignments are dealt to ranks by a hash of their steps
+    (see content_owner); "range": contiguous ranges balanced by step count
+    (shard_bounds).  Any partition gives the same summed counters.
     """
     aln_off = np.asarray(aln_off)
     aln_steps = np.asarray(aln_steps)
     if world_size == 1:
         return aln_off.astype(np.int32), aln_steps.astype(np.int32)
-    if policy == "range":
+    if policy == "product":
+        if n_nodes is None:
+            n_nodes = int(aln_steps.max() >> 1) + 1 if len(aln_steps) else 1
+        owner = product_owner(aln_off, aln_steps, n_nodes, world_size)
+    elif policy == "range":
         b = shard_bounds(aln_off, world_size)
         lo, hi = int(b[rank]), int(b[rank + 1])
         off = (aln_off[lo:hi + 1] - aln_off[lo]).astype(np.int32)
         steps = aln_steps[aln_off[lo]:aln_off[hi]].astype(np.int32)
         return off, steps
-    if policy != "content":
+    elif policy == "content":
+        owner = content_owner(aln_off, aln_steps, world_size)
+    else:
         raise ValueError("unknown sharding policy %r" % policy)
-    mine = np.flatnonzero(content_owner(aln_off, aln_steps, world_size) == rank)
+    mine = np.flatnonzero(owner == rank)
     m = (aln_off[mine + 1] - aln_off[mine]).astype(np.int64)
     off = np.zeros(len(mine) + 1, np.int64)
     np.cumsum(m, out=off[1:])

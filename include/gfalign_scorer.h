@@ -125,6 +125,16 @@ int gfal_scorer_create_dedup(const int32_t *aln_off, const int32_t *aln_steps,
                              const int32_t *universe, int32_t n_universe,
                              int32_t shard_index, int32_t n_shards, gfal_scorer **out);
 
+/*
+ * Which shard of gfal_scorer_create_sharded(..., shard, n_shards) takes each
+ * alignment: owner[k] in [0, n_shards).  Host code only (no HIP device needed):
+ * the ranks of a multi-GPU run all derive the same partition from the same
+ * input without communicating, and a test can check that on a CPU.
+ */
+int gfal_shard_owner(const int32_t *aln_off, const int32_t *aln_steps, int64_t n_aln,
+                     int32_t n_nodes, const int32_t *universe, int32_t n_universe,
+                     int32_t n_shards, int32_t *owner);
+
 void gfal_scorer_destroy(gfal_scorer *s);
 
 /*

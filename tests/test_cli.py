@@ -257,6 +257,47 @@ def test_search_on_a_synthetic_tangle_matches_oracle(cli, gpu, tmp_path):
     assert any(int(r.split("\t")[2]) > 0 for r in exp[:-1])   # non-zero good counters
 
 
+@pytest.mark.gpu
+def test_config5_flow_search_then_eval_path(cli, gpu, tmp_path):
+    """BASELINE config 5 at reduced size: `search` with the step cap given as an
+    integer literal (the reference parses -m with atoi, so "1e9" would mean one
+    step: src/main.cpp:462-464), alignments sharded over two scorers, then
+    `evalPath` on the best path the search printed (README.md:36-40 workflow).
+    The search rows are checked against oracle/search_oracle.py, the evalPath
+    rows and summary against oracle.pair_scores / oracle.evaluate_paths."""
+    import numpy as np
+    import oracle
+    t = synth.Tangle(V=60, n_T=50, N=3000, P=1, seed=25)
+    _write_tangle(t, str(tmp_path))
+    gfa, nodes, gaf = (str(tmp_path / n) for n in ("g.gfa", "nodes.tsv", "a.gaf"))
+    exp = search_oracle.search(gfa, nodes, "utig4-0", "utig4-59", gaf=gaf, max_steps=1000000000)
+    rc, out, err = run(cli, ["search", "-f", gfa, "-g", gaf, "-n", nodes, "-s", "utig4-0", "-d", "utig4-59",
+                             "-m", "1000000000", "--devices", "2"], env={"GFALIGN_SHARE_DEVICE": "1"})
+    assert rc == 0, err
+    rows = out.splitlines()
+    assert rows == exp and len(rows) >= 1 and "\t" in rows[-1]
+    best = rows[-1].split("\t")
+    path_text = best[7]
+    # evalPath on that path: every alignment (filter off), one row each + summary
+    rc, out, err = run(cli, ["evalPath", "-f", gfa, "-g", gaf, "-p", path_text, "--devices", "2"],
+                       env={"GFALIGN_SHARE_DEVICE": "1"})
+    assert rc == 0, err
+    lines = out.splitlines()
+    assert lines[0] == path_text and len(lines) == t.N + 2
+    ids = {"utig4-%d" % k: k for k in range(t.V)}
+    path = [(ids[c[:-1]] << 1) | int(c[-1] == "-") for c in path_text.split(",")]
+    fw, rcs = oracle.pair_scores(t.aln_off, t.aln_steps, path)
+    got_scores = [int(l.split("\t")[2]) for l in lines[1:-1]]
+    assert got_scores == np.maximum(fw, rcs).tolist()
+    bad, good, _ = oracle.evaluate_paths(t.aln_off, t.aln_steps, [0, len(path)], path, False)
+    uniques = len(set(s >> 1 for s in path))
+    assert lines[-1] == "%d\t%d\t%d\t%d\t%d" % (bad[0], good[0], int(bad[0]) - int(good[0]) - uniques,
+                                                 len(path), uniques)
+    # the search row (filter on) and the evalPath summary (filter off) differ only
+    # by the alignments with a node off the path
+    assert int(best[2]) <= int(good[0]) + int(bad[0])
+
+
 # ---- CLI behaviours of the reference beyond its .tst files (CPU) ----
 
 def test_graph_statistics_is_refused_not_ignored(cli):

@@ -1,10 +1,14 @@
 """CPU, world_size 2 over gloo: the multi-GPU contract of SURVEY.md 8(e).
 
-Each rank takes its shard of the alignments (gfalign_amd.shard), produces the
-per-path counters for the whole candidate batch, and the [3P] integer counters
-are summed with one all-reduce.  On the GPU box the per-rank scorer is the HIP
-path and the backend is RCCL; here the oracle stands in for the scorer so that
-the sharding and the collective can be checked without a GPU.
+Each rank takes its shard of the alignments -- the partition the PRODUCT makes
+(gfal_scorer_create_sharded keeps every n-th group of 64 of its own sorted
+order; gfal_shard_owner reports that assignment from host code, so it can be
+checked here) -- produces the per-path counters for the whole candidate batch,
+and the [3P] integer counters are summed with one all-reduce.  On the GPU box
+the per-rank scorer is the HIP path and the backend is RCCL
+(tests/test_gpu_multi_rank.py runs bench.py's N-rank path there); here the
+oracle stands in for the scorer so that the partition and the collective can be
+checked without a GPU.
 """
 import os
 import socket
@@ -29,7 +33,7 @@ def _rank_main(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     t = synth.make("smoke")
-    off, st = shard.take_shard(t.aln_off, t.aln_steps, rank, world)
+    off, st = shard.take_shard(t.aln_off, t.aln_steps, rank, world, policy="product", n_nodes=t.V)
     bad, good, una = oracle.evaluate_paths(off, st, t.path_off, t.path_steps, True)
     counts = torch.from_numpy(np.concatenate([bad, good, una]).astype(np.int32))
     shard.all_reduce_counts(counts)
@@ -69,6 +73,24 @@ def test_shard_bounds_cover_everything_once():
             assert total == t.N and steps == t.S
 
 
+def test_product_partition_is_what_the_library_reports():
+    """gfal_shard_owner (host half of gfal_scorer_create_sharded): every
+    alignment has exactly one owner, the shards balance, zero-step alignments go
+    to shard 0, and the same input gives the same partition every time (the
+    ranks never communicate about it)."""
+    t = synth.make("config2")
+    for world in (2, 3, 8):
+        owner = shard.product_owner(t.aln_off, t.aln_steps, t.V, world)
+        assert owner.min() == 0 and owner.max() == world - 1
+        steps = np.bincount(owner, weights=np.diff(t.aln_off).astype(np.float64), minlength=world)
+        assert steps.sum() == t.S and steps.max() - steps.min() < 0.03 * t.S / world
+        assert np.array_equal(owner, shard.product_owner(t.aln_off, t.aln_steps, t.V, world))
+    off = np.array([0, 0, 2, 2, 5], np.int32)         # two zero-step alignments
+    st = np.array([0, 2, 4, 2, 0], np.int32)
+    owner = shard.product_owner(off, st, 4, 3)
+    assert owner[0] == 0 and owner[2] == 0 and set(owner.tolist()) <= {0, 1, 2}
+
+
 def test_content_policy_keeps_copies_together():
     t = synth.make("config2")
     owner = shard.content_owner(t.aln_off, t.aln_steps, 8)
@@ -81,7 +103,7 @@ def test_content_policy_keeps_copies_together():
 def test_more_ranks_than_alignments():
     off = np.array([0, 2, 5], np.int32)
     st = np.arange(5, dtype=np.int32)
-    for policy in ("range", "content"):
+    for policy in ("range", "content", "product"):
         seen = 0
         for r in range(4):
             o, s = shard.take_shard(off, st, r, 4, policy)
