@@ -267,11 +267,11 @@ def test_config5_flow_search_then_eval_path(cli, gpu, tmp_path):
     rows and summary against oracle.pair_scores / oracle.evaluate_paths."""
     import numpy as np
     import oracle
-    t = synth.Tangle(V=60, n_T=50, N=3000, P=1, seed=25)
+    t = synth.Tangle(V=20, n_T=16, N=1500, P=1, seed=25)      # (the search runs until its queue is empty)
     _write_tangle(t, str(tmp_path))
     gfa, nodes, gaf = (str(tmp_path / n) for n in ("g.gfa", "nodes.tsv", "a.gaf"))
-    exp = search_oracle.search(gfa, nodes, "utig4-0", "utig4-59", gaf=gaf, max_steps=1000000000)
-    rc, out, err = run(cli, ["search", "-f", gfa, "-g", gaf, "-n", nodes, "-s", "utig4-0", "-d", "utig4-59",
+    exp = search_oracle.search(gfa, nodes, "utig4-0", "utig4-19", gaf=gaf, max_steps=1000000000)
+    rc, out, err = run(cli, ["search", "-f", gfa, "-g", gaf, "-n", nodes, "-s", "utig4-0", "-d", "utig4-19",
                              "-m", "1000000000", "--devices", "2"], env={"GFALIGN_SHARE_DEVICE": "1"})
     assert rc == 0, err
     rows = out.splitlines()
