@@ -510,7 +510,9 @@ __device__ __forceinline__ void push_pairs_to(unsigned long long *worklist,
 
 // The same for all tile paths of one item at once: bit p of fw / rc = this lane's
 // alignment is a candidate on tile path p.  One returning atomic per item (the
-// list cursor), fire-and-forget adds for the per-path histogram.
+// list cursor), fire-and-forget adds for the per-path histogram; the entries of
+// one path stay together (k_wl_scatter moves runs of equal (class, path) with one
+// atomic per run).
 __device__ __forceinline__ void push_item_pairs(unsigned long long *worklist,
                                                 unsigned long long *wl_count, uint32_t wl_capacity,
                                                 uint32_t *wl_hist, uint32_t *status, int n_paths,
@@ -519,33 +521,31 @@ __device__ __forceinline__ void push_item_pairs(unsigned long long *worklist,
 {
     const uint32_t any = fw | rc;
     if (!WAVE_ANY(any != 0u)) return;
-    const uint32_t mine = (uint32_t)__popc(any);
-    uint32_t incl = mine;                            // inclusive prefix over the lanes
-#pragma unroll
-    for (int o = 1; o < WAVE; o <<= 1) {
-        const uint32_t v = (uint32_t)__shfl_up((int)incl, o, WAVE);
-        if (lane >= o) incl += v;
+    const uint32_t cls = (uint32_t)length_class(M);
+    uint32_t total = 0;
+    for (int p = 0; p < tile_paths; ++p) {
+        const uint32_t c = (uint32_t)__popcll(WAVE_MASK(((any >> p) & 1u) != 0u));
+        if (c != 0u && lane == 0) atomicAdd(&wl_hist[cls * (uint32_t)n_paths + path0 + (uint32_t)p], c);
+        total += c;
     }
-    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, WAVE - 1);
     unsigned long long base = 0;
     if (lane == 0) base = atomicAdd(wl_count, (unsigned long long)total);
     base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(base >> 32), 0) << 32) |
            (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)base, 0);
-    const uint32_t cls = (uint32_t)length_class(M);
-    for (int p = 0; p < tile_paths; ++p) {
-        const lanemask m = WAVE_MASK(((any >> p) & 1u) != 0u);
-        if (m != 0 && lane == 0)
-            atomicAdd(&wl_hist[cls * (uint32_t)n_paths + path0 + (uint32_t)p], (uint32_t)__popcll(m));
-    }
-    unsigned long long idx = base + (incl - mine);
     bool overflow = false;
-    for (uint32_t left = any; left != 0u; left &= left - 1u, ++idx) {
-        const uint32_t p = (uint32_t)__builtin_ctz(left);
-        if (idx < wl_capacity)
-            worklist[idx] = (((fw >> p) & 1u) ? WL_FW : 0ull) | (((rc >> p) & 1u) ? WL_RC : 0ull) |
-                            ((unsigned long long)(path0 + p) << 32) | slot;
-        else
-            overflow = true;
+    for (int p = 0; p < tile_paths; ++p) {
+        const bool mine = ((any >> p) & 1u) != 0u;
+        const lanemask m = WAVE_MASK(mine);
+        if (m == 0) continue;
+        if (mine) {
+            const unsigned long long idx = base + lanes_below(m, lane);
+            if (idx < wl_capacity)
+                worklist[idx] = (((fw >> p) & 1u) ? WL_FW : 0ull) | (((rc >> p) & 1u) ? WL_RC : 0ull) |
+                                ((unsigned long long)(path0 + (uint32_t)p) << 32) | slot;
+            else
+                overflow = true;
+        }
+        base += (unsigned long long)__popcll(m);
     }
     if (overflow) atomicOr(status, ST_DP_OVERFLOW);
 }

@@ -427,32 +427,65 @@ def test_worklist_overflow_splits_the_batch(gpu, monkeypatch):
         assert np.array_equal(g, x)
 
 
+class _Hip:
+    """Device buffers for the device-resident API without torch (raw HIP runtime
+    through ctypes: the test process has usually initialised HIP through the scorer
+    library long before torch would)."""
+
+    def __init__(self):
+        import ctypes
+        self.c = ctypes
+        self.lib = ctypes.CDLL("libamdhip64.so")
+        self.lib.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+        self.lib.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        self.lib.hipFree.argtypes = [ctypes.c_void_p]
+        self.bufs = []
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        p = self.c.c_void_p()
+        assert self.lib.hipMalloc(self.c.byref(p), max(arr.nbytes, 4)) == 0
+        assert self.lib.hipMemcpy(p, arr.ctypes.data_as(self.c.c_void_p), arr.nbytes, 1) == 0   # H2D
+        self.bufs.append(p)
+        return p.value
+
+    def download(self, ptr, n, dtype):
+        out = np.zeros(n, dtype)
+        assert self.lib.hipDeviceSynchronize() == 0
+        assert self.lib.hipMemcpy(out.ctypes.data_as(self.c.c_void_p), self.c.c_void_p(ptr), out.nbytes, 2) == 0
+        return out
+
+    def free(self):
+        for p in self.bufs:
+            self.lib.hipFree(p)
+
+
 def test_device_api_reports_overflow_and_grows(gpu, monkeypatch):
     """score_device cannot re-run by itself: sync_status reports the overflow,
     grows the list, and the caller's second attempt fits."""
-    import torch
     rnd = random.Random(43)
     alns, paths = random_case(rnd, 2, 2000, 48, 7, 10, min_m=2, min_n=4)
     aoff, ast = csr(alns)
     poff, pst = csr(paths)
     exp = oracle.evaluate_paths(aoff, ast, poff, pst, True)
     monkeypatch.setenv("GFAL_DEBUG_WL_CAPACITY", "1")
-    dev = torch.device("cuda", 0)
-    d_off = torch.tensor(poff, dtype=torch.int32, device=dev)
-    d_st = torch.tensor(pst, dtype=torch.int32, device=dev)
-    d_cnt = torch.zeros(3 * len(paths), dtype=torch.int32, device=dev)
-    stream = torch.cuda.current_stream(dev).cuda_stream
-    with Scorer(aoff, ast, 4) as sc:
-        args = (d_off.data_ptr(), d_st.data_ptr(), len(paths), len(pst), max(len(p) for p in paths),
-                True, d_cnt.data_ptr(), stream)
-        sc.score_device(*args)
-        with pytest.raises(ScorerError) as e:
-            sc.sync_status()
-        assert e.value.code == -5 and "grown" in str(e.value)
-        sc.score_device(*args)
-        sc.sync_status()
-        counts = d_cnt.cpu().numpy().view(np.uint32)
     P = len(paths)
+    with Scorer(aoff, ast, 4) as sc:
+        hip = _Hip()
+        try:
+            d_off = hip.upload(np.asarray(poff, np.int32))
+            d_st = hip.upload(np.asarray(pst, np.int32))
+            d_cnt = hip.upload(np.zeros(3 * P, np.uint32))
+            args = (d_off, d_st, P, len(pst), max(len(p) for p in paths), True, d_cnt, 0)
+            sc.score_device(*args)
+            with pytest.raises(ScorerError) as e:
+                sc.sync_status()
+            assert e.value.code == -5 and "grown" in str(e.value)
+            sc.score_device(*args)
+            sc.sync_status()
+            counts = hip.download(d_cnt, 3 * P, np.uint32)
+        finally:
+            hip.free()
     for g, x in zip((counts[:P], counts[P:2 * P], counts[2 * P:]), exp):
         assert np.array_equal(g, x)
 
