@@ -715,6 +715,9 @@ int main(int argc, char **argv)
                     "scoring %.3f s)\n",
                     t_read - t_start, t_pack - t_read, t_open - t_pack, gfal::now_s() - t_open,
                     search.collect_seconds(), search.score_seconds());
+        if (verbose_flag && scorer.n_shards() > 1)
+            fprintf(stderr, "%zu devices, per-path counters summed %s\n", scorer.n_shards(),
+                    scorer.uses_rccl() ? "by an RCCL all-reduce" : "on the host");
         if (verbose_flag)
             fprintf(stderr, "scored %llu candidate paths in %llu batches (%llu pairs took the exact DP)\n",
                     (unsigned long long)search.scored_paths(),

@@ -28,6 +28,7 @@
 //
 // No MFMA anywhere: the work is integer compares and LDS table lookups.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <atomic>
@@ -37,6 +38,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <exception>
+#include <memory>
 #include <new>
 #include <thread>
 #include <vector>
@@ -2945,6 +2947,10 @@ struct gfal_scorer {
     hipEvent_t dp_fork = nullptr, dp_join[3] = {nullptr, nullptr, nullptr};
 
     int64_t n_score_calls = 0, n_device_passes = 0, n_overflow_reruns = 0;
+    // status words of the last blocking call (they came back with its counters):
+    // gfal_scorer_get_info then needs no device round trip (a search asks after every batch)
+    bool status_cached = false;
+    uint32_t cached_status[8] = {};
     hipEvent_t order_ev = nullptr;     // orders a call behind the previous one on another stream
 
     // last call
@@ -3831,6 +3837,7 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
         HIP_TRY(hipStreamWaitEvent(st, s->order_ev, 0));
     }
     ++s->n_device_passes;
+    s->status_cached = false;
 
     const ImageLayout L = make_layout(s->n_local, max_path_len);
     const size_t img_bytes = (size_t)L.total * sizeof(uint16_t);
@@ -4175,6 +4182,29 @@ int gfal_scorer_sync_status(gfal_scorer *s)
     return rc;
 }
 
+// Blocking-API staging without the wait: paths into the pinned buffer and onto the
+// device, the kernels enqueued on the scorer's stream, counters left in
+// s->d_counts[0 .. 3P) and the status words behind them (gfal_group_score).
+static int score_stage(gfal_scorer *s, const int32_t *path_off, const int32_t *path_steps, int32_t P,
+                       int32_t max_len, int filter)
+{
+    const int64_t total = path_off[P];
+    const size_t n_in = (size_t)P + 1 + (size_t)total, n_out = (size_t)3 * P + 4;
+    int rc;
+    if ((rc = dev_reserve(&s->d_path_off, &s->path_off_cap, n_in))) return rc;
+    if ((rc = dev_reserve(&s->d_counts, &s->counts_cap, n_out))) return rc;
+    if ((rc = pinned_reserve(&s->h_in, &s->h_in_cap, n_in))) return rc;
+    if ((rc = pinned_reserve(&s->h_out, &s->h_out_cap, n_out))) return rc;
+    memcpy(s->h_in, path_off, ((size_t)P + 1) * sizeof(int32_t));
+    memcpy(s->h_in + P + 1, path_steps, (size_t)total * sizeof(int32_t));
+    HIP_TRY(hipMemcpyAsync(s->d_path_off, s->h_in, n_in * sizeof(int32_t), hipMemcpyHostToDevice, s->stream));
+    rc = score_device_impl(s, s->d_path_off, s->d_path_off + P + 1, P, total, max_len, filter, s->d_counts,
+                           s->stream, s->d_counts + (size_t)3 * P);
+    s->last_stream = s->stream;
+    s->have_last = true;
+    return rc;
+}
+
 static int score_range(gfal_scorer *s, const int32_t *path_off,
                        const int32_t *path_steps, int32_t lo, int32_t hi,
                        int32_t max_len, int filter, uint32_t *bad, uint32_t *good,
@@ -4242,6 +4272,8 @@ static int score_range(gfal_scorer *s, const int32_t *path_off,
     s->last_stream = s->stream;
     s->have_last = true;
     HIP_TRY(hipStreamSynchronize(s->stream));
+    memcpy(s->cached_status, s->h_out + (size_t)3 * P, 4 * sizeof(uint32_t));
+    s->status_cached = true;
     rc = status_to_code(s, s->h_out + (size_t)3 * P);
     if (rc == GFAL_E_NOMEM) {
         // Worklist overflow.  The pass counted every pair it wanted to append, so
@@ -4302,6 +4334,197 @@ int gfal_scorer_score(gfal_scorer *s, const int32_t *path_off,
         return score_range(s, path_off, path_steps, 0, n_paths, max_len, filter, bad, good,
                            unaligned);
     });
+}
+
+// --------------------------------------------------------------------------
+// Scorer groups: the shards of one alignment set on the GPUs of one node, in one
+// process.  Every device scores the whole batch against its shard; the per-path
+// counters (uint32[3P]: 120 KB at 10 k paths, latency-bound) are summed where
+// they are, by ONE RCCL all-reduce over xGMI (ncclAllReduce inside a group call,
+// one communicator per device from ncclCommInitAll), and only device 0's copy
+// travels to the host.  RCCL is loaded on first use (dlopen: a scorer that is
+// never grouped does not pay for loading it).  When RCCL cannot serve the group
+// -- library missing, or two shards share a device (test rigs) -- the counters
+// are copied out per shard and added on the host: same integers either way.
+// --------------------------------------------------------------------------
+namespace {
+struct Rccl {
+    typedef void *comm_t;
+    int (*CommInitAll)(comm_t *, int, const int *) = nullptr;
+    int (*CommDestroy)(comm_t) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, comm_t, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    void *lib = nullptr;
+    bool load()
+    {
+        if (lib) return true;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (lib) break;
+        }
+        if (!lib) return false;
+        CommInitAll = reinterpret_cast<decltype(CommInitAll)>(dlsym(lib, "ncclCommInitAll"));
+        CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+        AllReduce = reinterpret_cast<decltype(AllReduce)>(dlsym(lib, "ncclAllReduce"));
+        GroupStart = reinterpret_cast<decltype(GroupStart)>(dlsym(lib, "ncclGroupStart"));
+        GroupEnd = reinterpret_cast<decltype(GroupEnd)>(dlsym(lib, "ncclGroupEnd"));
+        GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+        return CommInitAll && CommDestroy && AllReduce && GroupStart && GroupEnd;
+    }
+};
+constexpr int NCCL_UINT32 = 3, NCCL_SUM = 0;      // ncclDataType_t / ncclRedOp_t (rccl.h)
+}  // namespace
+
+struct gfal_group {
+    std::vector<gfal_scorer *> shards;
+    Rccl rccl;
+    std::vector<Rccl::comm_t> comms;          // empty: host sums
+    std::vector<uint32_t> h_sum;              // host-sum scratch
+};
+
+static int score_stage(gfal_scorer *s, const int32_t *path_off, const int32_t *path_steps, int32_t P,
+                       int32_t max_len, int filter);
+
+int gfal_group_create(gfal_scorer *const *scorers, int n, gfal_group **out)
+{
+    if (!out || !scorers || n < 1) return GFAL_E_ARG;
+    *out = nullptr;
+    return no_throw([&] {
+        std::unique_ptr<gfal_group> g(new gfal_group());
+        std::vector<int> devs;
+        bool distinct = true;
+        for (int i = 0; i < n; ++i) {
+            if (!scorers[i]) return GFAL_E_ARG;
+            for (int d : devs) distinct &= d != scorers[i]->device;
+            devs.push_back(scorers[i]->device);
+            g->shards.push_back(scorers[i]);
+        }
+        const char *off = getenv("GFAL_GROUP_HOST_SUM");
+        if (distinct && !(off && atoi(off)) && g->rccl.load()) {
+            g->comms.assign((size_t)n, nullptr);
+            const int rc = g->rccl.CommInitAll(g->comms.data(), n, devs.data());
+            if (rc != 0) {
+                (void)hipGetLastError();
+                g->comms.clear();             // RCCL cannot serve this group: sums on the host
+            }
+        }
+        *out = g.release();
+        return GFAL_OK;
+    });
+}
+
+void gfal_group_destroy(gfal_group *g)
+{
+    if (!g) return;
+    for (Rccl::comm_t c : g->comms)
+        if (c) (void)g->rccl.CommDestroy(c);
+    delete g;
+}
+
+int gfal_group_uses_rccl(const gfal_group *g) { return g && !g->comms.empty() ? 1 : 0; }
+
+static int group_score_impl(gfal_group *g, const int32_t *path_off, const int32_t *path_steps,
+                            int32_t n_paths, int filter, uint32_t *bad, uint32_t *good,
+                            uint32_t *unaligned)
+{
+    const size_t D = g->shards.size();
+    const int32_t P = n_paths;
+    int32_t max_len = 1;
+    for (int32_t p = 0; p < P; ++p) {
+        const int64_t n = (int64_t)path_off[p + 1] - path_off[p];
+        if (n < 1 || n > GFAL_MAX_STEPS) {
+            set_err("path %d has %lld steps (allowed 1..%d)", p, (long long)n, GFAL_MAX_STEPS);
+            return GFAL_E_RANGE;
+        }
+        max_len = std::max(max_len, (int32_t)n);
+    }
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        // every device: paths in, the kernels (no host wait in between)
+        for (size_t d = 0; d < D; ++d) {
+            gfal_scorer *s = g->shards[d];
+            HIP_TRY(hipSetDevice(s->device));
+            ++s->n_score_calls;
+            const int rc = score_stage(s, path_off, path_steps, P, max_len, filter);
+            if (rc) return rc;
+        }
+        const size_t n_cnt = (size_t)3 * P;
+        if (!g->comms.empty()) {
+            // sum the counters where they are: one all-reduce over the group
+            int rc = g->rccl.GroupStart();
+            for (size_t d = 0; d < D && rc == 0; ++d) {
+                gfal_scorer *s = g->shards[d];
+                (void)hipSetDevice(s->device);
+                rc = g->rccl.AllReduce(s->d_counts, s->d_counts, n_cnt, NCCL_UINT32, NCCL_SUM, g->comms[d],
+                                       s->stream);
+            }
+            const int rc2 = g->rccl.GroupEnd();
+            if (rc != 0 || rc2 != 0) {
+                set_err("RCCL all-reduce failed: %s",
+                        g->rccl.GetErrorString ? g->rccl.GetErrorString(rc ? rc : rc2) : "?");
+                return GFAL_E_HIP;
+            }
+        }
+        // counters (device 0's after an all-reduce, every shard's otherwise) and status words out
+        for (size_t d = 0; d < D; ++d) {
+            gfal_scorer *s = g->shards[d];
+            HIP_TRY(hipSetDevice(s->device));
+            const bool need_counts = g->comms.empty() || d == 0;
+            if (need_counts)
+                HIP_TRY(hipMemcpyAsync(s->h_out, s->d_counts, n_cnt * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                                       s->stream));
+            // the status words were copied behind the counters by k_unpermute BEFORE the
+            // all-reduce touched the first 3P words
+            HIP_TRY(hipMemcpyAsync(s->h_out + n_cnt, s->d_counts + n_cnt, 4 * sizeof(uint32_t),
+                                   hipMemcpyDeviceToHost, s->stream));
+        }
+        bool again = false;
+        for (size_t d = 0; d < D; ++d) {
+            gfal_scorer *s = g->shards[d];
+            HIP_TRY(hipSetDevice(s->device));
+            HIP_TRY(hipStreamSynchronize(s->stream));
+            const uint32_t *st4 = s->h_out + n_cnt;
+            memcpy(s->cached_status, st4, 4 * sizeof(uint32_t));
+            s->status_cached = true;
+            const int rc = status_to_code(s, st4);
+            if (rc == GFAL_E_NOMEM) {        // worklist overflow on this shard: grow, run the group again
+                const unsigned long long need = (unsigned long long)st4[2] | ((unsigned long long)st4[3] << 32);
+                ++s->n_overflow_reruns;
+                const int grown = grow_worklist(s, need);
+                if (grown) return grown;
+                again = true;
+            } else if (rc) {
+                return rc;
+            }
+        }
+        if (again) continue;
+        if (!g->comms.empty()) {
+            const uint32_t *h = g->shards[0]->h_out;
+            memcpy(bad, h, (size_t)P * sizeof(uint32_t));
+            memcpy(good, h + P, (size_t)P * sizeof(uint32_t));
+            if (unaligned) memcpy(unaligned, h + 2 * (size_t)P, (size_t)P * sizeof(uint32_t));
+        } else {
+            g->h_sum.assign(n_cnt, 0u);
+            for (size_t d = 0; d < D; ++d)
+                for (size_t k = 0; k < n_cnt; ++k) g->h_sum[k] += g->shards[d]->h_out[k];
+            memcpy(bad, g->h_sum.data(), (size_t)P * sizeof(uint32_t));
+            memcpy(good, g->h_sum.data() + P, (size_t)P * sizeof(uint32_t));
+            if (unaligned) memcpy(unaligned, g->h_sum.data() + 2 * (size_t)P, (size_t)P * sizeof(uint32_t));
+        }
+        return GFAL_OK;
+    }
+    set_err("exact-DP worklist kept overflowing");
+    return GFAL_E_NOMEM;
+}
+
+int gfal_group_score(gfal_group *g, const int32_t *path_off, const int32_t *path_steps, int32_t n_paths,
+                     int filter, uint32_t *bad, uint32_t *good, uint32_t *unaligned)
+{
+    if (!g || n_paths < 0) return GFAL_E_ARG;
+    if (n_paths == 0) return GFAL_OK;
+    if (!path_off || !path_steps || !bad || !good || path_off[0] != 0) return GFAL_E_ARG;
+    return no_throw([&] { return group_score_impl(g, path_off, path_steps, n_paths, filter, bad, good, unaligned); });
 }
 
 static int pair_scores_impl(gfal_scorer *s, const int32_t *path_steps, int32_t n,
@@ -4423,9 +4646,13 @@ int gfal_scorer_get_info(gfal_scorer *s, gfal_info *out)
     if (s->have_last) {
         HIP_TRY(hipSetDevice(s->device));
         uint32_t host[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        HIP_TRY(hipMemcpyAsync(host, s->d_status, sizeof(host), hipMemcpyDeviceToHost,
-                               s->last_stream));
-        HIP_TRY(hipStreamSynchronize(s->last_stream));
+        if (s->status_cached && !s->profiling) {
+            memcpy(host, s->cached_status, sizeof(host));
+        } else {
+            HIP_TRY(hipMemcpyAsync(host, s->d_status, sizeof(host), hipMemcpyDeviceToHost,
+                                   s->last_stream));
+            HIP_TRY(hipStreamSynchronize(s->last_stream));
+        }
         out->dp_pairs = (int64_t)((unsigned long long)host[2] | ((unsigned long long)host[3] << 32));
 #ifdef GFAL_STAMPS
         {

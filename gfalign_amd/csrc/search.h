@@ -156,21 +156,17 @@ struct PackedAlignments {
 };
 
 // The alignments, sharded over one or more MI355X: one
-// gfal_scorer per device, alignments dealt by content (see open()); every device
-// scores the whole batch against its shard (one host thread each, so the
-// devices run concurrently) and the per-path integer counters are added up.
+// gfal_scorer per device (each keeps its share of the set, see open()), grouped
+// (gfal_group): every device scores the whole batch against its shard -- the
+// kernels of all devices are enqueued before anything is waited for -- and the
+// per-path integer counters are summed by one RCCL all-reduce over xGMI.
 // Scoring with zero alignments never touches a device (the loop of
 // src/eval.cpp:80 has no iterations: all counters are zero).
 class PathScorer {
 public:
     ~PathScorer()
     {
-        {
-            std::lock_guard<std::mutex> lk(mu_);
-            stop_ = true;
-        }
-        cv_.notify_all();
-        for (auto &t : workers_) t.join();
+        if (group_) gfal_group_destroy(group_);
         for (gfal_scorer *h : shards_)
             if (h) gfal_scorer_destroy(h);
     }
@@ -212,8 +208,19 @@ public:
                         errs[(size_t)d].c_str());
                 return false;
             }
+        if (n_devices > 1) {
+            // the shards as one group: counters summed on the devices by one RCCL
+            // all-reduce over xGMI (on the host if RCCL cannot serve the group, e.g.
+            // all shards on one device)
+            const int rc = gfal_group_create(shards_.data(), n_devices, &group_);
+            if (rc != GFAL_OK) {
+                fprintf(stderr, "Error: scorer group: %s (%s)\n", gfal_strerror(rc), gfal_last_error());
+                return false;
+            }
+        }
         return true;
     }
+    bool uses_rccl() const { return group_ && gfal_group_uses_rccl(group_); }
     bool score(const std::vector<int32_t> &off, const std::vector<int32_t> &steps, bool filter,
                std::vector<uint32_t> &bad, std::vector<uint32_t> &good)
     {
@@ -221,44 +228,17 @@ public:
         bad.assign(P, 0);
         good.assign(P, 0);
         if (n_aln_ == 0 || P == 0) return true;
-        const size_t D = shards_.size();
-        std::vector<std::vector<uint32_t>> pb(D, std::vector<uint32_t>(P)), pg(D, std::vector<uint32_t>(P));
-        std::vector<int> rcs(D, GFAL_OK);
-        std::vector<std::string> errs(D);
-        std::function<void(size_t)> work = [&](size_t d) {
-            rcs[d] = gfal_scorer_score(shards_[d], off.data(), steps.data(), (int32_t)P,
-                                       filter ? 1 : 0, pb[d].data(), pg[d].data(), nullptr);
-            if (rcs[d] != GFAL_OK) errs[d] = gfal_last_error();
-        };
-        // one persistent worker per further device (a search makes thousands of
-        // calls: no thread start-up per batch); this thread takes device 0
-        if (workers_.empty() && D > 1) start_workers(D);
-        if (D > 1) {
-            {
-                std::lock_guard<std::mutex> lk(mu_);
-                job_ = &work;
-                pending_ = D - 1;
-                ++generation_;
-            }
-            cv_.notify_all();
+        const int rc = group_ ? gfal_group_score(group_, off.data(), steps.data(), (int32_t)P, filter ? 1 : 0,
+                                                 bad.data(), good.data(), nullptr)
+                              : gfal_scorer_score(shards_[0], off.data(), steps.data(), (int32_t)P,
+                                                  filter ? 1 : 0, bad.data(), good.data(), nullptr);
+        if (rc != GFAL_OK) {
+            fprintf(stderr, "Error: scorer: %s (%s)\n", gfal_strerror(rc), gfal_last_error());
+            return false;
         }
-        work(0);
-        if (D > 1) {
-            std::unique_lock<std::mutex> lk(mu_);
-            done_cv_.wait(lk, [&] { return pending_ == 0; });
-            job_ = nullptr;
-        }
-        for (size_t d = 0; d < D; ++d) {
-            if (rcs[d] != GFAL_OK) {
-                fprintf(stderr, "Error: scorer: %s (%s)\n", gfal_strerror(rcs[d]), errs[d].c_str());
-                return false;
-            }
-            for (size_t k = 0; k < P; ++k) {
-                bad[k] += pb[d][k];
-                good[k] += pg[d][k];
-            }
+        for (gfal_scorer *h : shards_) {
             gfal_info info;
-            if (gfal_scorer_get_info(shards_[d], &info) == GFAL_OK) dp_pairs_ += (uint64_t)info.dp_pairs;
+            if (gfal_scorer_get_info(h, &info) == GFAL_OK) dp_pairs_ += (uint64_t)info.dp_pairs;
         }
         return true;
     }
@@ -283,38 +263,8 @@ public:
     size_t n_shards() const { return shards_.size(); }
 
 private:
-    void start_workers(size_t n_devices)
-    {
-        for (size_t d = 1; d < n_devices; ++d)
-            workers_.emplace_back([this, d] {
-                uint64_t seen = 0;
-                while (true) {
-                    std::function<void(size_t)> *job;
-                    {
-                        std::unique_lock<std::mutex> lk(mu_);
-                        cv_.wait(lk, [&] { return stop_ || generation_ != seen; });
-                        if (stop_) return;
-                        seen = generation_;
-                        job = job_;
-                    }
-                    (*job)(d);
-                    {
-                        std::lock_guard<std::mutex> lk(mu_);
-                        --pending_;
-                    }
-                    done_cv_.notify_one();
-                }
-            });
-    }
-
     std::vector<gfal_scorer *> shards_;
-    std::vector<std::thread> workers_;
-    std::mutex mu_;
-    std::condition_variable cv_, done_cv_;
-    std::function<void(size_t)> *job_ = nullptr;
-    size_t pending_ = 0;
-    uint64_t generation_ = 0;
-    bool stop_ = false;
+    gfal_group *group_ = nullptr;
     int64_t n_aln_ = 0;
     uint64_t dp_pairs_ = 0;
 };

@@ -59,6 +59,12 @@ EXPORTS = {
                                                 ctypes.c_int64, ctypes.c_int32,
                                                 ctypes.c_int, ctypes.c_void_p,
                                                 ctypes.c_void_p]),
+    "gfal_group_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int,
+                                         ctypes.POINTER(ctypes.c_void_p)]),
+    "gfal_group_destroy": (None, [ctypes.c_void_p]),
+    "gfal_group_uses_rccl": (ctypes.c_int, [ctypes.c_void_p]),
+    "gfal_group_score": (ctypes.c_int, [ctypes.c_void_p, _i32p, _i32p, ctypes.c_int32, ctypes.c_int,
+                                        _u32p, _u32p, _u32p]),
     "gfal_scorer_sync_status": (ctypes.c_int, [ctypes.c_void_p]),
     "gfal_scorer_pair_scores": (ctypes.c_int, [ctypes.c_void_p, _i32p, ctypes.c_int32,
                                                _i32p, _i32p]),
@@ -238,3 +244,40 @@ class Scorer:
 def device_count():
     n = load_library().gfal_device_count()
     return max(n, 0)
+
+
+class Group:
+    """The shards of one alignment set scored together (gfal_group_*): counters
+    summed by one RCCL all-reduce on the devices, or on the host when RCCL cannot
+    serve the group (`uses_rccl`)."""
+
+    def __init__(self, scorers):
+        self._lib = load_library()
+        self._scorers = list(scorers)                 # keep them alive
+        arr = (ctypes.c_void_p * len(self._scorers))(*[s._h for s in self._scorers])
+        self._h = ctypes.c_void_p()
+        _check(self._lib.gfal_group_create(arr, len(self._scorers), ctypes.byref(self._h)))
+
+    @property
+    def uses_rccl(self):
+        return bool(self._lib.gfal_group_uses_rccl(self._h))
+
+    def evaluate_paths(self, path_off, path_steps, filter=True):
+        path_off, path_steps = _i32(path_off), _i32(path_steps)
+        P = len(path_off) - 1
+        bad, good, una = (np.zeros(P, np.uint32) for _ in range(3))
+        _check(self._lib.gfal_group_score(
+            self._h, _ptr(path_off, ctypes.c_int32), _ptr(path_steps, ctypes.c_int32), P, int(bool(filter)),
+            _ptr(bad, ctypes.c_uint32), _ptr(good, ctypes.c_uint32), _ptr(una, ctypes.c_uint32)))
+        return bad, good, una
+
+    def close(self):
+        if self._h:
+            self._lib.gfal_group_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

@@ -169,6 +169,26 @@ int gfal_scorer_score_device(gfal_scorer *s,
                              int32_t max_path_len, int filter,
                              uint32_t *d_counts, void *hip_stream);
 
+/*
+ * The shards of one alignment set on the GPUs of one node, in one process
+ * (multi-GPU without torch / MPI: what `gfalign search --devices N` uses).
+ * gfal_group_score is gfal_scorer_score for the whole set: every device scores
+ * the batch against its shard, the per-path counters are summed on the devices
+ * by one RCCL all-reduce over xGMI (uint32[3P]) and device 0's copy comes back.
+ * RCCL is loaded on first use; if it cannot serve the group (library missing,
+ * two shards on one device) the counters are added on the host instead --
+ * gfal_group_uses_rccl tells which.  The scorers stay owned by the caller and
+ * must outlive the group; one host thread at a time.
+ */
+typedef struct gfal_group gfal_group;
+int  gfal_group_create(gfal_scorer *const *scorers, int n, gfal_group **out);
+void gfal_group_destroy(gfal_group *g);
+int  gfal_group_uses_rccl(const gfal_group *g);
+int  gfal_group_score(gfal_group *g,
+                      const int32_t *path_off, const int32_t *path_steps,
+                      int32_t n_paths, int filter,
+                      uint32_t *bad, uint32_t *good, uint32_t *unaligned);
+
 /* Status word of the most recent score_device call (blocks on its stream). */
 int gfal_scorer_sync_status(gfal_scorer *s);
 

@@ -187,3 +187,38 @@ def test_many_nodes_need_no_chain_images(gpu):
     exp = oracle.evaluate_paths(aoff, ast, poff, pst, True)
     for g, f, e in zip(got, few, exp):
         assert np.array_equal(g, e) and np.array_equal(f, e[:8])
+
+
+def test_scorer_groups_sum_with_rccl_or_on_the_host(gpu, monkeypatch):
+    """gfal_group_*: the shards of a set scored together.  One shard per device:
+    the counters are summed by an RCCL all-reduce on the devices (a one-GPU box
+    can only form the one-rank group, which still runs ncclAllReduce); shards that
+    share a device, or GFAL_GROUP_HOST_SUM=1: summed on the host.  Same integers."""
+    from gfalign_amd.scorer import Group
+    rnd = random.Random(81)
+    alns, paths = walk_case(rnd, 20, 100, 5000, 120, 10)
+    aoff, ast = csr(alns)
+    poff, pst = csr(paths)
+    exp = oracle.evaluate_paths(aoff, ast, poff, pst, True)
+    with Scorer(aoff, ast, 32) as sc, Group([sc]) as g:
+        assert g.uses_rccl
+        for _ in range(2):
+            got = g.evaluate_paths(poff, pst, True)
+            for a, e in zip(got, exp):
+                assert np.array_equal(a, e)
+    shards = [Scorer(aoff, ast, 32, shard=(k, 3)) for k in range(3)]
+    try:
+        with Group(shards) as g:
+            assert not g.uses_rccl                       # three shards on one device
+            got = g.evaluate_paths(poff, pst, True)
+    finally:
+        for s in shards:
+            s.close()
+    for a, e in zip(got, exp):
+        assert np.array_equal(a, e)
+    monkeypatch.setenv("GFAL_GROUP_HOST_SUM", "1")
+    with Scorer(aoff, ast, 32) as sc, Group([sc]) as g:
+        assert not g.uses_rccl
+        got = g.evaluate_paths(poff, pst, False)
+    for a, e in zip(got, oracle.evaluate_paths(aoff, ast, poff, pst, False)):
+        assert np.array_equal(a, e)
