@@ -4195,8 +4195,10 @@ static int score_stage(gfal_scorer *s, const int32_t *path_off, const int32_t *p
     if ((rc = dev_reserve(&s->d_counts, &s->counts_cap, n_out))) return rc;
     if ((rc = pinned_reserve(&s->h_in, &s->h_in_cap, n_in))) return rc;
     if ((rc = pinned_reserve(&s->h_out, &s->h_out_cap, n_out))) return rc;
-    memcpy(s->h_in, path_off, ((size_t)P + 1) * sizeof(int32_t));
-    memcpy(s->h_in + P + 1, path_steps, (size_t)total * sizeof(int32_t));
+    if (path_off != s->h_in) {      // (a re-run stages from this very buffer)
+        memcpy(s->h_in, path_off, ((size_t)P + 1) * sizeof(int32_t));
+        memcpy(s->h_in + P + 1, path_steps, (size_t)total * sizeof(int32_t));
+    }
     HIP_TRY(hipMemcpyAsync(s->d_path_off, s->h_in, n_in * sizeof(int32_t), hipMemcpyHostToDevice, s->stream));
     rc = score_device_impl(s, s->d_path_off, s->d_path_off + P + 1, P, total, max_len, filter, s->d_counts,
                            s->stream, s->d_counts + (size_t)3 * P);
@@ -4382,6 +4384,10 @@ struct gfal_group {
     Rccl rccl;
     std::vector<Rccl::comm_t> comms;          // empty: host sums
     std::vector<uint32_t> h_sum;              // host-sum scratch
+    // the batch between gfal_group_score_begin and _end
+    bool pending = false;
+    int32_t pend_paths = 0, pend_max_len = 0;
+    int pend_filter = 0;
 };
 
 static int score_stage(gfal_scorer *s, const int32_t *path_off, const int32_t *path_steps, int32_t P,
@@ -4402,7 +4408,10 @@ int gfal_group_create(gfal_scorer *const *scorers, int n, gfal_group **out)
             g->shards.push_back(scorers[i]);
         }
         const char *off = getenv("GFAL_GROUP_HOST_SUM");
-        if (distinct && !(off && atoi(off)) && g->rccl.load()) {
+        // (a group of one has nothing to sum; GFAL_GROUP_RCCL_SINGLE=1 runs the one-rank
+        // all-reduce anyway: the only RCCL a one-GPU test box can exercise)
+        const char *single = getenv("GFAL_GROUP_RCCL_SINGLE");
+        if (distinct && (n > 1 || (single && atoi(single))) && !(off && atoi(off)) && g->rccl.load()) {
             g->comms.assign((size_t)n, nullptr);
             const int rc = g->rccl.CommInitAll(g->comms.data(), n, devs.data());
             if (rc != 0) {
@@ -4425,14 +4434,59 @@ void gfal_group_destroy(gfal_group *g)
 
 int gfal_group_uses_rccl(const gfal_group *g) { return g && !g->comms.empty() ? 1 : 0; }
 
-static int group_score_impl(gfal_group *g, const int32_t *path_off, const int32_t *path_steps,
-                            int32_t n_paths, int filter, uint32_t *bad, uint32_t *good,
-                            uint32_t *unaligned)
+// every device: paths in, the kernels, the all-reduce, counters and status words
+// on their way out -- nothing waited for
+static int group_enqueue(gfal_group *g, const int32_t *path_off, const int32_t *path_steps)
 {
     const size_t D = g->shards.size();
-    const int32_t P = n_paths;
+    const int32_t P = g->pend_paths;
+    for (size_t d = 0; d < D; ++d) {
+        gfal_scorer *s = g->shards[d];
+        HIP_TRY(hipSetDevice(s->device));
+        const int rc = score_stage(s, path_off, path_steps, P, g->pend_max_len, g->pend_filter);
+        if (rc) return rc;
+    }
+    const size_t n_cnt = (size_t)3 * P;
+    if (!g->comms.empty()) {
+        // sum the counters where they are: one all-reduce over the group
+        int rc = g->rccl.GroupStart();
+        for (size_t d = 0; d < D && rc == 0; ++d) {
+            gfal_scorer *s = g->shards[d];
+            (void)hipSetDevice(s->device);
+            rc = g->rccl.AllReduce(s->d_counts, s->d_counts, n_cnt, NCCL_UINT32, NCCL_SUM, g->comms[d],
+                                   s->stream);
+        }
+        const int rc2 = g->rccl.GroupEnd();
+        if (rc != 0 || rc2 != 0) {
+            set_err("RCCL all-reduce failed: %s",
+                    g->rccl.GetErrorString ? g->rccl.GetErrorString(rc ? rc : rc2) : "?");
+            return GFAL_E_HIP;
+        }
+    }
+    // counters (device 0's after an all-reduce, every shard's otherwise) and status words out
+    for (size_t d = 0; d < D; ++d) {
+        gfal_scorer *s = g->shards[d];
+        HIP_TRY(hipSetDevice(s->device));
+        if (g->comms.empty() || d == 0)
+            HIP_TRY(hipMemcpyAsync(s->h_out, s->d_counts, n_cnt * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                                   s->stream));
+        // (k_unpermute put the status words behind the counters BEFORE the all-reduce
+        // touched the first 3P words)
+        HIP_TRY(hipMemcpyAsync(s->h_out + n_cnt, s->d_counts + n_cnt, 4 * sizeof(uint32_t),
+                               hipMemcpyDeviceToHost, s->stream));
+    }
+    return GFAL_OK;
+}
+
+static int group_begin_impl(gfal_group *g, const int32_t *path_off, const int32_t *path_steps,
+                            int32_t n_paths, int filter)
+{
+    if (g->pending) {
+        set_err("gfal_group_score_begin: the previous batch has not been collected");
+        return GFAL_E_ARG;
+    }
     int32_t max_len = 1;
-    for (int32_t p = 0; p < P; ++p) {
+    for (int32_t p = 0; p < n_paths; ++p) {
         const int64_t n = (int64_t)path_off[p + 1] - path_off[p];
         if (n < 1 || n > GFAL_MAX_STEPS) {
             set_err("path %d has %lld steps (allowed 1..%d)", p, (long long)n, GFAL_MAX_STEPS);
@@ -4440,45 +4494,33 @@ static int group_score_impl(gfal_group *g, const int32_t *path_off, const int32_
         }
         max_len = std::max(max_len, (int32_t)n);
     }
-    for (int attempt = 0; attempt < 3; ++attempt) {
-        // every device: paths in, the kernels (no host wait in between)
-        for (size_t d = 0; d < D; ++d) {
-            gfal_scorer *s = g->shards[d];
-            HIP_TRY(hipSetDevice(s->device));
-            ++s->n_score_calls;
-            const int rc = score_stage(s, path_off, path_steps, P, max_len, filter);
-            if (rc) return rc;
+    for (int64_t t = 0; t < path_off[n_paths]; ++t) {
+        const int32_t st = path_steps[t];
+        if (st < 0 || ((st & ~GFAL_STEP_OTHER) >> 1) >= g->shards[0]->n_nodes) {
+            set_err("path step %lld: node id out of range", (long long)t);
+            return GFAL_E_RANGE;
         }
-        const size_t n_cnt = (size_t)3 * P;
-        if (!g->comms.empty()) {
-            // sum the counters where they are: one all-reduce over the group
-            int rc = g->rccl.GroupStart();
-            for (size_t d = 0; d < D && rc == 0; ++d) {
-                gfal_scorer *s = g->shards[d];
-                (void)hipSetDevice(s->device);
-                rc = g->rccl.AllReduce(s->d_counts, s->d_counts, n_cnt, NCCL_UINT32, NCCL_SUM, g->comms[d],
-                                       s->stream);
-            }
-            const int rc2 = g->rccl.GroupEnd();
-            if (rc != 0 || rc2 != 0) {
-                set_err("RCCL all-reduce failed: %s",
-                        g->rccl.GetErrorString ? g->rccl.GetErrorString(rc ? rc : rc2) : "?");
-                return GFAL_E_HIP;
-            }
-        }
-        // counters (device 0's after an all-reduce, every shard's otherwise) and status words out
-        for (size_t d = 0; d < D; ++d) {
-            gfal_scorer *s = g->shards[d];
-            HIP_TRY(hipSetDevice(s->device));
-            const bool need_counts = g->comms.empty() || d == 0;
-            if (need_counts)
-                HIP_TRY(hipMemcpyAsync(s->h_out, s->d_counts, n_cnt * sizeof(uint32_t), hipMemcpyDeviceToHost,
-                                       s->stream));
-            // the status words were copied behind the counters by k_unpermute BEFORE the
-            // all-reduce touched the first 3P words
-            HIP_TRY(hipMemcpyAsync(s->h_out + n_cnt, s->d_counts + n_cnt, 4 * sizeof(uint32_t),
-                                   hipMemcpyDeviceToHost, s->stream));
-        }
+    }
+    g->pend_paths = n_paths;
+    g->pend_max_len = max_len;
+    g->pend_filter = filter;
+    for (gfal_scorer *s : g->shards) ++s->n_score_calls;
+    const int rc = group_enqueue(g, path_off, path_steps);
+    g->pending = rc == GFAL_OK;
+    return rc;
+}
+
+static int group_end_impl(gfal_group *g, uint32_t *bad, uint32_t *good, uint32_t *unaligned)
+{
+    if (!g->pending) {
+        set_err("gfal_group_score_end without a batch");
+        return GFAL_E_ARG;
+    }
+    g->pending = false;
+    const size_t D = g->shards.size();
+    const int32_t P = g->pend_paths;
+    const size_t n_cnt = (size_t)3 * P;
+    for (int attempt = 0; attempt < 4; ++attempt) {
         bool again = false;
         for (size_t d = 0; d < D; ++d) {
             gfal_scorer *s = g->shards[d];
@@ -4488,7 +4530,7 @@ static int group_score_impl(gfal_group *g, const int32_t *path_off, const int32_
             memcpy(s->cached_status, st4, 4 * sizeof(uint32_t));
             s->status_cached = true;
             const int rc = status_to_code(s, st4);
-            if (rc == GFAL_E_NOMEM) {        // worklist overflow on this shard: grow, run the group again
+            if (rc == GFAL_E_NOMEM) {        // worklist overflow on this shard: grow, run the batch again
                 const unsigned long long need = (unsigned long long)st4[2] | ((unsigned long long)st4[3] << 32);
                 ++s->n_overflow_reruns;
                 const int grown = grow_worklist(s, need);
@@ -4498,24 +4540,43 @@ static int group_score_impl(gfal_group *g, const int32_t *path_off, const int32_
                 return rc;
             }
         }
-        if (again) continue;
-        if (!g->comms.empty()) {
-            const uint32_t *h = g->shards[0]->h_out;
-            memcpy(bad, h, (size_t)P * sizeof(uint32_t));
-            memcpy(good, h + P, (size_t)P * sizeof(uint32_t));
-            if (unaligned) memcpy(unaligned, h + 2 * (size_t)P, (size_t)P * sizeof(uint32_t));
-        } else {
-            g->h_sum.assign(n_cnt, 0u);
-            for (size_t d = 0; d < D; ++d)
-                for (size_t k = 0; k < n_cnt; ++k) g->h_sum[k] += g->shards[d]->h_out[k];
-            memcpy(bad, g->h_sum.data(), (size_t)P * sizeof(uint32_t));
-            memcpy(good, g->h_sum.data() + P, (size_t)P * sizeof(uint32_t));
-            if (unaligned) memcpy(unaligned, g->h_sum.data() + 2 * (size_t)P, (size_t)P * sizeof(uint32_t));
+        if (!again) {
+            if (!g->comms.empty() || D == 1) {
+                const uint32_t *h = g->shards[0]->h_out;
+                memcpy(bad, h, (size_t)P * sizeof(uint32_t));
+                memcpy(good, h + P, (size_t)P * sizeof(uint32_t));
+                if (unaligned) memcpy(unaligned, h + 2 * (size_t)P, (size_t)P * sizeof(uint32_t));
+            } else {
+                g->h_sum.assign(n_cnt, 0u);
+                for (size_t d = 0; d < D; ++d)
+                    for (size_t k = 0; k < n_cnt; ++k) g->h_sum[k] += g->shards[d]->h_out[k];
+                memcpy(bad, g->h_sum.data(), (size_t)P * sizeof(uint32_t));
+                memcpy(good, g->h_sum.data() + P, (size_t)P * sizeof(uint32_t));
+                if (unaligned) memcpy(unaligned, g->h_sum.data() + 2 * (size_t)P, (size_t)P * sizeof(uint32_t));
+            }
+            return GFAL_OK;
         }
-        return GFAL_OK;
+        // the batch is still in shard 0's pinned staging buffer: [offsets | steps]
+        const int32_t *h_in = g->shards[0]->h_in;
+        const int rc = group_enqueue(g, h_in, h_in + P + 1);
+        if (rc) return rc;
     }
     set_err("exact-DP worklist kept overflowing");
     return GFAL_E_NOMEM;
+}
+
+int gfal_group_score_begin(gfal_group *g, const int32_t *path_off, const int32_t *path_steps,
+                           int32_t n_paths, int filter)
+{
+    if (!g || n_paths < 1) return GFAL_E_ARG;
+    if (!path_off || !path_steps || path_off[0] != 0) return GFAL_E_ARG;
+    return no_throw([&] { return group_begin_impl(g, path_off, path_steps, n_paths, filter); });
+}
+
+int gfal_group_score_end(gfal_group *g, uint32_t *bad, uint32_t *good, uint32_t *unaligned)
+{
+    if (!g || !bad || !good) return GFAL_E_ARG;
+    return no_throw([&] { return group_end_impl(g, bad, good, unaligned); });
 }
 
 int gfal_group_score(gfal_group *g, const int32_t *path_off, const int32_t *path_steps, int32_t n_paths,
@@ -4523,8 +4584,9 @@ int gfal_group_score(gfal_group *g, const int32_t *path_off, const int32_t *path
 {
     if (!g || n_paths < 0) return GFAL_E_ARG;
     if (n_paths == 0) return GFAL_OK;
-    if (!path_off || !path_steps || !bad || !good || path_off[0] != 0) return GFAL_E_ARG;
-    return no_throw([&] { return group_score_impl(g, path_off, path_steps, n_paths, filter, bad, good, unaligned); });
+    const int rc = gfal_group_score_begin(g, path_off, path_steps, n_paths, filter);
+    if (rc) return rc;
+    return gfal_group_score_end(g, bad, good, unaligned);
 }
 
 static int pair_scores_impl(gfal_scorer *s, const int32_t *path_steps, int32_t n,

@@ -208,30 +208,38 @@ public:
                         errs[(size_t)d].c_str());
                 return false;
             }
-        if (n_devices > 1) {
-            // the shards as one group: counters summed on the devices by one RCCL
-            // all-reduce over xGMI (on the host if RCCL cannot serve the group, e.g.
-            // all shards on one device)
-            const int rc = gfal_group_create(shards_.data(), n_devices, &group_);
-            if (rc != GFAL_OK) {
-                fprintf(stderr, "Error: scorer group: %s (%s)\n", gfal_strerror(rc), gfal_last_error());
-                return false;
-            }
+        // the shards as one group: counters summed on the devices by one RCCL
+        // all-reduce over xGMI (on the host if RCCL cannot serve the group, e.g. all
+        // shards on one device; a group of one has nothing to sum)
+        const int rc = gfal_group_create(shards_.data(), n_devices, &group_);
+        if (rc != GFAL_OK) {
+            fprintf(stderr, "Error: scorer group: %s (%s)\n", gfal_strerror(rc), gfal_last_error());
+            return false;
         }
         return true;
     }
     bool uses_rccl() const { return group_ && gfal_group_uses_rccl(group_); }
-    bool score(const std::vector<int32_t> &off, const std::vector<int32_t> &steps, bool filter,
-               std::vector<uint32_t> &bad, std::vector<uint32_t> &good)
+    // A batch in two halves: begin() hands it to the devices and returns (the
+    // vectors may be reused at once), end() waits for the counters.
+    bool begin(const std::vector<int32_t> &off, const std::vector<int32_t> &steps, bool filter)
     {
-        const size_t P = off.size() - 1;
+        pending_paths_ = off.size() - 1;
+        if (n_aln_ == 0 || pending_paths_ == 0) return true;
+        const int rc = gfal_group_score_begin(group_, off.data(), steps.data(), (int32_t)pending_paths_,
+                                              filter ? 1 : 0);
+        if (rc != GFAL_OK) {
+            fprintf(stderr, "Error: scorer: %s (%s)\n", gfal_strerror(rc), gfal_last_error());
+            return false;
+        }
+        return true;
+    }
+    bool end(std::vector<uint32_t> &bad, std::vector<uint32_t> &good)
+    {
+        const size_t P = pending_paths_;
         bad.assign(P, 0);
         good.assign(P, 0);
         if (n_aln_ == 0 || P == 0) return true;
-        const int rc = group_ ? gfal_group_score(group_, off.data(), steps.data(), (int32_t)P, filter ? 1 : 0,
-                                                 bad.data(), good.data(), nullptr)
-                              : gfal_scorer_score(shards_[0], off.data(), steps.data(), (int32_t)P,
-                                                  filter ? 1 : 0, bad.data(), good.data(), nullptr);
+        const int rc = gfal_group_score_end(group_, bad.data(), good.data(), nullptr);
         if (rc != GFAL_OK) {
             fprintf(stderr, "Error: scorer: %s (%s)\n", gfal_strerror(rc), gfal_last_error());
             return false;
@@ -241,6 +249,11 @@ public:
             if (gfal_scorer_get_info(h, &info) == GFAL_OK) dp_pairs_ += (uint64_t)info.dp_pairs;
         }
         return true;
+    }
+    bool score(const std::vector<int32_t> &off, const std::vector<int32_t> &steps, bool filter,
+               std::vector<uint32_t> &bad, std::vector<uint32_t> &good)
+    {
+        return begin(off, steps, filter) && end(bad, good);
     }
     uint64_t dp_pairs() const { return dp_pairs_; }   // pairs that needed the exact DP so far
     // fw / rc traceback scores of one path against every alignment, in input order
@@ -265,6 +278,7 @@ public:
 private:
     std::vector<gfal_scorer *> shards_;
     gfal_group *group_ = nullptr;
+    size_t pending_paths_ = 0;
     int64_t n_aln_ = 0;
     uint64_t dp_pairs_ = 0;
 };
@@ -275,6 +289,11 @@ struct SearchOptions {
     uint32_t min_nodes = 0;
     bool return_all_paths = false;
     size_t speculate = 128;        // candidate paths scored per GPU batch (target)
+    // GFALIGN_PREFETCH=1: keep one further batch in flight while the host pops.  Measured
+    // on config 3 (-m 20000): the batch in flight holds what is needed next 88 % of the
+    // time, but the search stalls every few pops, so there is little host work to hide and
+    // the extra batches cost more than they save (0.24 s against 0.19 s): off by default.
+    bool prefetch = false;
 };
 
 // reference src/eval.cpp:110-193
@@ -284,7 +303,9 @@ struct SearchOptions {
 // path, and so are the extensions themselves (orientation gate, budgets), so
 // whenever the front entry has no scored extensions yet, its whole subtree is
 // generated breadth-first -- and that of the next best queue entries -- until
-// about `speculate` candidate paths are collected; they are scored in ONE call.
+// about `speculate` candidate paths are collected; they are scored in ONE call
+// (gfal_group_score_begin / _end: optionally the next batch is handed to the
+// devices before the host returns to popping, see SearchOptions::prefetch).
 // Entries are still popped, extended, enqueued and printed in exactly the
 // reference's order; speculation that is never popped is only wasted work.
 class Search {
@@ -326,13 +347,14 @@ public:
         auto first = std::make_unique<Node>();
         first->path.push_back(GFAL_STEP_OTHER | (int32_t)(src_uid << 1));   // :130, orientation '0'
         first->uniques = 1;
+        first->scored = true;           // (never scored: its key is 0 by definition, :132)
         queue_.emplace(Key{0, seq_++}, std::move(first));                   // :132
 
         uint64_t path_counter = 0;
         uint32_t steps = 0, best_uniques = 0;
         int32_t best_alt = INT32_MAX;
         while (!queue_.empty() && steps < opt_.max_steps) {                 // :134
-            if (!queue_.begin()->second->kids_scored && !expand_front()) return EXIT_FAILURE;
+            if (!queue_.begin()->second->kids_scored && !score_front()) return EXIT_FAILURE;
             std::unique_ptr<Node> u = std::move(queue_.begin()->second);    // :135
             queue_.erase(queue_.begin());
             for (std::unique_ptr<Node> &c : u->kids) {                      // :136-185
@@ -362,11 +384,14 @@ public:
         }
         if (steps >= opt_.max_steps)                                        // :190-191
             out_ << "Reached maximum number of steps (" << steps << ")" << std::endl;
+        if (in_flight_ && !finish()) return EXIT_FAILURE;                   // (drain the device)
         return EXIT_SUCCESS;
     }
 
     uint64_t scored_paths() const { return scored_; }
     uint64_t batches() const { return batches_; }
+    uint64_t prefetch_hits() const { return prefetch_hits_; }
+    uint64_t prefetch_misses() const { return prefetch_misses_; }
     double collect_seconds() const { return t_collect_; }
     double score_seconds() const { return t_score_; }
 
@@ -380,6 +405,7 @@ private:
         std::vector<int32_t> path;      // packed steps, as the scorer takes them
         uint32_t uniques = 0, bad = 0, good = 0;
         bool at_destination = false;
+        bool scored = false;            // bad / good are known (queue entries, finished batches)
         bool kids_made = false, kids_scored = false;
         std::vector<std::unique_ptr<Node>> kids;   // extensions, adjacency order
     };
@@ -422,61 +448,112 @@ private:
         }
     }
 
-    // Generate and score, in one batch, the unscored part of the subtrees under
-    // the best queue entries (front first), breadth-first.
-    bool expand_front()
+    int32_t key_of(const Node &n) const
+    {
+        return (int32_t)n.bad - (int32_t)n.good - (int32_t)n.uniques;        // :163
+    }
+
+    // Collect the next batch: breadth-first under the best queue entries (front
+    // first), through the nodes that already have their extensions -- scored or in
+    // flight: extending a path needs no counters -- down to the first nodes without,
+    // until about `budget` candidates are gathered.  The search mostly dives under
+    // its front entry, so the levels below it are what it asks for next.
+    void collect(size_t budget)
     {
         const double t0 = now_s();
-        std::vector<Node *> level, parents;   // parents: nodes whose kids get scored now
-        std::vector<int32_t> off{0}, steps;
+        batch_parents_.clear();
+        batch_off_.assign(1, 0);
+        batch_steps_.clear();
         size_t n_paths = 0;
+        level_.clear();
         auto it = queue_.begin();
         // roots: the front entry always; further entries while there is room
-        while (it != queue_.end() && (level.empty() || n_paths + level.size() < opt_.speculate / 4)) {
-            level.push_back(it->second.get());
+        while (it != queue_.end() && (level_.empty() || n_paths + level_.size() < budget / 4)) {
+            level_.push_back(it->second.get());
             ++it;
-            if (level.size() >= 64) break;
+            if (level_.size() >= 64) break;
         }
-        while (!level.empty() && n_paths < opt_.speculate) {
-            std::vector<Node *> next;
-            for (Node *e : level) {
-                if (n_paths >= opt_.speculate && e != queue_.begin()->second.get()) break;
+        Node *front = queue_.begin()->second.get();
+        while (!level_.empty() && n_paths < budget) {
+            next_.clear();
+            for (Node *e : level_) {
+                if (n_paths >= budget && e != front) break;
                 if (!e->kids_made) {
                     make_kids(*e);
-                    parents.push_back(e);
+                    batch_parents_.push_back(e);
                     for (auto &c : e->kids) {
-                        steps.insert(steps.end(), c->path.begin(), c->path.end());
-                        off.push_back((int32_t)steps.size());
+                        batch_steps_.insert(batch_steps_.end(), c->path.begin(), c->path.end());
+                        batch_off_.push_back((int32_t)batch_steps_.size());
                         ++n_paths;
                     }
                 }
                 for (auto &c : e->kids)
-                    if (!c->at_destination && c->path.size() < GFAL_MAX_STEPS) next.push_back(c.get());
+                    if (!c->at_destination && c->path.size() < GFAL_MAX_STEPS) next_.push_back(c.get());
             }
-            level.swap(next);
+            level_.swap(next_);
         }
-        std::vector<uint32_t> bad, good;
-        if (dump_) {   // GFALIGN_DUMP_BATCHES: the candidate batches, for benchmarks
-            const int32_t head[2] = {(int32_t)n_paths, (int32_t)steps.size()};
+        if (dump_ && n_paths) {   // GFALIGN_DUMP_BATCHES: the candidate batches, for benchmarks
+            const int32_t head[2] = {(int32_t)n_paths, (int32_t)batch_steps_.size()};
             fwrite(head, sizeof(int32_t), 2, dump_);
-            fwrite(off.data(), sizeof(int32_t), off.size(), dump_);
-            fwrite(steps.data(), sizeof(int32_t), steps.size(), dump_);
+            fwrite(batch_off_.data(), sizeof(int32_t), batch_off_.size(), dump_);
+            fwrite(batch_steps_.data(), sizeof(int32_t), batch_steps_.size(), dump_);
         }
-        const double t1 = now_s();
-        t_collect_ += t1 - t0;
-        if (!scorer_.score(off, steps, true, bad, good)) return false;   // :162
-        t_score_ += now_s() - t1;
+        t_collect_ += now_s() - t0;
+    }
+
+    bool submit()
+    {
+        if (batch_off_.size() <= 1) return true;            // nothing to score
+        const double t0 = now_s();
+        if (!scorer_.begin(batch_off_, batch_steps_, true)) return false;     // :162
+        flight_parents_.swap(batch_parents_);
+        in_flight_ = true;
+        t_score_ += now_s() - t0;
+        return true;
+    }
+
+    bool finish()
+    {
+        const double t0 = now_s();
+        if (!scorer_.end(bad_, good_)) return false;
         size_t k = 0;
-        for (Node *e : parents) {
+        for (Node *e : flight_parents_) {
             for (auto &c : e->kids) {
-                c->bad = bad[k];
-                c->good = good[k];
+                c->bad = bad_[k];
+                c->good = good_[k];
+                c->scored = true;
                 ++k;
             }
             e->kids_scored = true;
         }
+        flight_parents_.clear();
+        in_flight_ = false;
         scored_ += k;
         ++batches_;
+        t_score_ += now_s() - t0;
+        return true;
+    }
+
+    // The front entry needs its extensions' counters.  They are in the batch in
+    // flight, or a batch is made for them now; either way the next batch goes out
+    // before the host returns to popping.
+    bool score_front()
+    {
+        Node *f = queue_.begin()->second.get();
+        if (in_flight_) {
+            ++(f->kids_made ? prefetch_hits_ : prefetch_misses_);
+            if (!finish()) return false;
+        }
+        if (!f->kids_scored) {
+            collect(opt_.speculate);
+            if (!submit()) return false;
+            if (in_flight_ && !finish()) return false;
+            if (!f->kids_scored) f->kids_scored = true;     // (no extensions at all)
+        }
+        if (opt_.prefetch && opt_.speculate > 1) {
+            collect(opt_.speculate);
+            if (!submit()) return false;
+        }
         return true;
     }
 
@@ -490,6 +567,12 @@ private:
     std::map<Key, std::unique_ptr<Node>> queue_;
     uint64_t seq_ = 0, scored_ = 0, batches_ = 0;
     double t_collect_ = 0, t_score_ = 0;
+    // the batch being collected, and the parents of the one the devices are scoring
+    std::vector<Node *> batch_parents_, flight_parents_, level_, next_;
+    uint64_t prefetch_hits_ = 0, prefetch_misses_ = 0;
+    std::vector<int32_t> batch_off_, batch_steps_;
+    std::vector<uint32_t> bad_, good_;
+    bool in_flight_ = false;
     FILE *dump_ = nullptr;
 };
 

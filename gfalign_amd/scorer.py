@@ -65,6 +65,8 @@ EXPORTS = {
     "gfal_group_uses_rccl": (ctypes.c_int, [ctypes.c_void_p]),
     "gfal_group_score": (ctypes.c_int, [ctypes.c_void_p, _i32p, _i32p, ctypes.c_int32, ctypes.c_int,
                                         _u32p, _u32p, _u32p]),
+    "gfal_group_score_begin": (ctypes.c_int, [ctypes.c_void_p, _i32p, _i32p, ctypes.c_int32, ctypes.c_int]),
+    "gfal_group_score_end": (ctypes.c_int, [ctypes.c_void_p, _u32p, _u32p, _u32p]),
     "gfal_scorer_sync_status": (ctypes.c_int, [ctypes.c_void_p]),
     "gfal_scorer_pair_scores": (ctypes.c_int, [ctypes.c_void_p, _i32p, ctypes.c_int32,
                                                _i32p, _i32p]),
@@ -269,6 +271,20 @@ class Group:
         _check(self._lib.gfal_group_score(
             self._h, _ptr(path_off, ctypes.c_int32), _ptr(path_steps, ctypes.c_int32), P, int(bool(filter)),
             _ptr(bad, ctypes.c_uint32), _ptr(good, ctypes.c_uint32), _ptr(una, ctypes.c_uint32)))
+        return bad, good, una
+
+    def begin(self, path_off, path_steps, filter=True):
+        path_off, path_steps = _i32(path_off), _i32(path_steps)
+        self._pending_paths = len(path_off) - 1
+        _check(self._lib.gfal_group_score_begin(
+            self._h, _ptr(path_off, ctypes.c_int32), _ptr(path_steps, ctypes.c_int32),
+            self._pending_paths, int(bool(filter))))
+
+    def end(self):
+        P = self._pending_paths
+        bad, good, una = (np.zeros(P, np.uint32) for _ in range(3))
+        _check(self._lib.gfal_group_score_end(self._h, _ptr(bad, ctypes.c_uint32), _ptr(good, ctypes.c_uint32),
+                                              _ptr(una, ctypes.c_uint32)))
         return bad, good, una
 
     def close(self):

@@ -188,6 +188,17 @@ int  gfal_group_score(gfal_group *g,
                       const int32_t *path_off, const int32_t *path_steps,
                       int32_t n_paths, int filter,
                       uint32_t *bad, uint32_t *good, uint32_t *unaligned);
+/*
+ * The same in two halves, so that the caller can work while the devices score:
+ * _begin copies the batch into pinned staging (the host buffers are free again
+ * on return) and enqueues everything -- copies in, kernels, all-reduce, copies
+ * out; _end waits for it and hands the counters over.  One batch at a time.
+ * `gfalign search` prepares its next candidate batch between the two.
+ */
+int  gfal_group_score_begin(gfal_group *g,
+                            const int32_t *path_off, const int32_t *path_steps,
+                            int32_t n_paths, int filter);
+int  gfal_group_score_end(gfal_group *g, uint32_t *bad, uint32_t *good, uint32_t *unaligned);
 
 /* Status word of the most recent score_device call (blocks on its stream). */
 int gfal_scorer_sync_status(gfal_scorer *s);

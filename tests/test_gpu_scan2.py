@@ -200,12 +200,22 @@ def test_scorer_groups_sum_with_rccl_or_on_the_host(gpu, monkeypatch):
     aoff, ast = csr(alns)
     poff, pst = csr(paths)
     exp = oracle.evaluate_paths(aoff, ast, poff, pst, True)
+    monkeypatch.setenv("GFAL_GROUP_RCCL_SINGLE", "1")       # (a group of one normally skips the all-reduce)
     with Scorer(aoff, ast, 32) as sc, Group([sc]) as g:
         assert g.uses_rccl
         for _ in range(2):
             got = g.evaluate_paths(poff, pst, True)
             for a, e in zip(got, exp):
                 assert np.array_equal(a, e)
+        g.begin(poff, pst, False)                           # the two halves, with host work in between
+        other = oracle.evaluate_paths(aoff, ast, poff, pst, False)
+        for a, e in zip(g.end(), other):
+            assert np.array_equal(a, e)
+    monkeypatch.delenv("GFAL_GROUP_RCCL_SINGLE")
+    with Scorer(aoff, ast, 32) as sc, Group([sc]) as g:
+        assert not g.uses_rccl
+        for a, e in zip(g.evaluate_paths(poff, pst, True), exp):
+            assert np.array_equal(a, e)
     shards = [Scorer(aoff, ast, 32, shard=(k, 3)) for k in range(3)]
     try:
         with Group(shards) as g:
