@@ -50,6 +50,13 @@ namespace {
 constexpr int WAVE = 64;
 constexpr int SCAN_THREADS = 768;
 constexpr int SCAN_WAVES = SCAN_THREADS / WAVE;
+#ifndef GFAL_SCAN2_THREADS
+#define GFAL_SCAN2_THREADS 1024
+#endif
+constexpr int SCAN2_THREADS = GFAL_SCAN2_THREADS;      // k_scan2: two workgroups per CU = 8 waves per SIMD (64 VGPRs);
+                                                       // 768 threads (6 waves, 80 VGPRs) measured 4 % slower
+constexpr int SCAN2_WAVES = SCAN2_THREADS / WAVE;
+constexpr int SCAN2_WAVES_PER_SIMD = 2 * SCAN2_THREADS / 256;
 constexpr int MAX_REG_K = 16;          // alignments of up to 2K+1 = 33 steps are compared
                                        // from registers (K pair dwords per lane)
 constexpr int MAX_REG_M = 16;          // smallest step-array capacity of an image
@@ -1357,7 +1364,7 @@ __device__ __forceinline__ void insert_windows(uint16_t *steps, int nm, uint32_t
     const int n_win = n - M + 1;                 // windows per strand
     const int P0 = (M + 1) / 2;
     uint32_t fresh = 0;                          // entries this thread created
-    for (int w = tid; w < 2 * n_win; w += SCAN_THREADS) {
+    for (int w = tid; w < 2 * n_win; w += SCAN2_THREADS) {
         const uint32_t strand = w >= n_win ? 1u : 0u;
         const uint32_t pos = (uint32_t)(strand ? w - n_win : w);
         const uint32_t idx = ((uint32_t)p * 2u + strand) * (uint32_t)nm + pos;
@@ -1429,7 +1436,7 @@ __device__ __forceinline__ void common_prefix(const uint16_t *steps, int nm, int
 {
     const uint32_t *a = reinterpret_cast<const uint32_t *>(steps + (size_t)p * 2 * nm);
     const uint32_t *b = reinterpret_cast<const uint32_t *>(steps + (size_t)q * 2 * nm);
-    for (int i = tid; 2 * i < n; i += SCAN_THREADS) {
+    for (int i = tid; 2 * i < n; i += SCAN2_THREADS) {
         const uint32_t x = a[i] ^ b[i];
         if (x) atomicMin(out, (uint32_t)(2 * i + ((x & 0xFFFFu) ? 0 : 1)));
     }
@@ -1699,7 +1706,7 @@ __device__ __forceinline__ void scan2_items(const Scan2Args &a, const Tile2 &tv,
                                             int chunk, int wave, int lane, Counts &wc)
 {
     const int n_chunks = (int)sg.n_chunks;
-    const int item_stride = SCAN_WAVES * n_chunks;
+    const int item_stride = SCAN2_WAVES * n_chunks;
     const int M = (int)sg.m;
     const uint32_t ulane = (uint32_t)lane;
     for (int it0 = (int)sg.item_lo + chunk + wave * n_chunks; it0 < (int)sg.item_hi;
@@ -1778,7 +1785,7 @@ __device__ __forceinline__ void scan2_items(const Scan2Args &a, const Tile2 &tv,
 }
 
 template <bool W, bool NM8>
-__global__ __launch_bounds__(SCAN_THREADS, 6) void k_scan2(Scan2Args a)
+__global__ __launch_bounds__(SCAN2_THREADS, SCAN2_WAVES_PER_SIMD) void k_scan2(Scan2Args a)
 {
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
     const int tid = threadIdx.x;
@@ -1838,10 +1845,10 @@ __global__ __launch_bounds__(SCAN_THREADS, 6) void k_scan2(Scan2Args a)
     // Stage the steps of the tile's paths (forward | reverse complement: contiguous
     // in the image, 4-byte aligned) and build the node masks from the node ids along
     // the paths.  Every global load of the prologue is issued before the first one is
-    // waited for: SCAN_THREADS / TILE2_MAX threads per path, each with its share of
+    // waited for: SCAN2_THREADS / TILE2_MAX threads per path, each with its share of
     // the path's dwords in registers (one exposed memory latency, not one per loop
     // trip and path).
-    constexpr int PER_PATH = SCAN_THREADS / TILE2_MAX;                   // 96 threads (NM8: 7 paths use them)
+    constexpr int PER_PATH = SCAN2_THREADS / TILE2_MAX;                   // 96 threads (NM8: 7 paths use them)
     constexpr int STEP_LOADS = (GFAL_MAX_STEPS + 8 + PER_PATH - 1) / PER_PATH;          // nm dwords
     constexpr int LID_LOADS = ((GFAL_MAX_STEPS + 8) / 2 + PER_PATH - 1) / PER_PATH;     // nm / 2 dwords
     const int my_p = tid / PER_PATH, my_q = tid % PER_PATH;
@@ -1868,12 +1875,12 @@ __global__ __launch_bounds__(SCAN_THREADS, 6) void k_scan2(Scan2Args a)
         tv.hdr_n = a.images[(size_t)(tv.path0 + lane) * a.L.total + a.L.len_at()];
     // meanwhile: node masks, table and counters start empty
     if constexpr (NM8) {
-        for (int v = tid; v < (a.L.v2 + 3) / 4; v += SCAN_THREADS) nodemask[v] = NOT_A0_8 * 0x01010101u;
+        for (int v = tid; v < (a.L.v2 + 3) / 4; v += SCAN2_THREADS) nodemask[v] = NOT_A0_8 * 0x01010101u;
     } else {
-        for (int v = tid; v < a.L.v2; v += SCAN_THREADS) nodemask[v] = NOT_A0;
+        for (int v = tid; v < a.L.v2; v += SCAN2_THREADS) nodemask[v] = NOT_A0;
     }
-    for (int i = tid; i < H_SLOTS; i += SCAN_THREADS) table[i] = H_EMPTY;
-    for (int i = tid; i < H_SLOTS / 4; i += SCAN_THREADS) maskw[i] = 0;
+    for (int i = tid; i < H_SLOTS; i += SCAN2_THREADS) table[i] = H_EMPTY;
+    for (int i = tid; i < H_SLOTS / 4; i += SCAN2_THREADS) maskw[i] = 0;
     if (tid < 16) misc[tid] = 0;               // [0] entries, [1] overflow flag, [2 + t] common prefixes
     __syncthreads();
     if (have_p) {
@@ -1925,8 +1932,8 @@ __global__ __launch_bounds__(SCAN_THREADS, 6) void k_scan2(Scan2Args a)
         while (true) {                         // further rounds only after an overflow
             __syncthreads();
             if (!fresh_table) {
-                for (int i = tid; i < H_SLOTS; i += SCAN_THREADS) table[i] = H_EMPTY;
-                for (int i = tid; i < H_SLOTS / 4; i += SCAN_THREADS) maskw[i] = 0;
+                for (int i = tid; i < H_SLOTS; i += SCAN2_THREADS) table[i] = H_EMPTY;
+                for (int i = tid; i < H_SLOTS / 4; i += SCAN2_THREADS) maskw[i] = 0;
                 if (tid < 2) misc[tid] = 0;    // [0] entries, [1] overflow flag
             }
             fresh_table = false;
@@ -3964,7 +3971,7 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
             // that for filling the GPU, as k_scan does
             const int64_t items2 = item_lo_chain;
             int y_want = (want_groups + a2.n_tiles - 1) / a2.n_tiles;
-            int min_items = 100 * SCAN_WAVES;
+            int min_items = 100 * SCAN2_WAVES;
             if (a2.n_tiles < slots) {          // fewer tiles than resident workgroups: fill the GPU
                 // quarter rounds of the resident workgroups to aim for: every workgroup
                 // pays a prologue, so a search-sized batch (128 paths: 16 tiles) wants
@@ -3973,7 +3980,7 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
                 int rounds4 = a2.n_tiles <= 40 ? 4 : 8;
                 if (const char *env = getenv("GFAL_SCAN2_ROUNDS4")) rounds4 = std::max(1, atoi(env));
                 y_want = std::min(y_want, (rounds4 * slots / 4 + a2.n_tiles - 1) / a2.n_tiles);
-                min_items = 12 * SCAN_WAVES;
+                min_items = 12 * SCAN2_WAVES;
             }
             a2.chunk_mult = (((unsigned long long)y_want << 24) + (unsigned long long)items2 - 1) /
                             (unsigned long long)std::max<int64_t>(items2, 1);
@@ -3989,11 +3996,11 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
                 }
                 const unsigned grid2 = (unsigned)a2.n_tiles * y_total;
                 if (s->d_item_weight) {
-                    if (nm8) hipLaunchKernelGGL((k_scan2<true, true>), dim3(grid2), dim3(SCAN_THREADS), lds2, st, a2);
-                    else hipLaunchKernelGGL((k_scan2<true, false>), dim3(grid2), dim3(SCAN_THREADS), lds2, st, a2);
+                    if (nm8) hipLaunchKernelGGL((k_scan2<true, true>), dim3(grid2), dim3(SCAN2_THREADS), lds2, st, a2);
+                    else hipLaunchKernelGGL((k_scan2<true, false>), dim3(grid2), dim3(SCAN2_THREADS), lds2, st, a2);
                 } else {
-                    if (nm8) hipLaunchKernelGGL((k_scan2<false, true>), dim3(grid2), dim3(SCAN_THREADS), lds2, st, a2);
-                    else hipLaunchKernelGGL((k_scan2<false, false>), dim3(grid2), dim3(SCAN_THREADS), lds2, st, a2);
+                    if (nm8) hipLaunchKernelGGL((k_scan2<false, true>), dim3(grid2), dim3(SCAN2_THREADS), lds2, st, a2);
+                    else hipLaunchKernelGGL((k_scan2<false, false>), dim3(grid2), dim3(SCAN2_THREADS), lds2, st, a2);
                 }
                 HIP_TRY(hipGetLastError());
                 s->last_grid += (int)grid2;
