@@ -1845,25 +1845,31 @@ __global__ __launch_bounds__(SCAN2_THREADS, SCAN2_WAVES_PER_SIMD) void k_scan2(S
     // Stage the steps of the tile's paths (forward | reverse complement: contiguous
     // in the image, 4-byte aligned) and build the node masks from the node ids along
     // the paths.  Every global load of the prologue is issued before the first one is
-    // waited for: SCAN2_THREADS / TILE2_MAX threads per path, each with its share of
-    // the path's dwords in registers (one exposed memory latency, not one per loop
-    // trip and path).
-    constexpr int PER_PATH = SCAN2_THREADS / TILE2_MAX;                   // 96 threads (NM8: 7 paths use them)
-    constexpr int STEP_LOADS = (GFAL_MAX_STEPS + 8 + PER_PATH - 1) / PER_PATH;          // nm dwords
+    // waited for (one exposed memory latency, not one per loop trip and path).
+    // (a) the steps go straight from global memory into LDS (LDS-DMA: no registers
+    // in between; lane l of a wave-instruction lands at its uniform LDS base + 4 l)
+    {
+        const int chunks = (nm + WAVE - 1) / WAVE;                        // 64 dwords each
+        for (int c = wave; c < tv.tile_paths * chunks; c += SCAN2_WAVES) {
+            const int p = c / chunks, o = (c % chunks) * WAVE;
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(
+                a.images + (size_t)(tv.path0 + p) * a.L.total + a.L.step_at()) + o;
+            uint32_t *dst = reinterpret_cast<uint32_t *>(steps + (size_t)p * 2 * nm) + o;
+            if (o + lane < nm)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(src + lane),
+                    (__attribute__((address_space(3))) void *)dst, 4, 0, 0);
+        }
+    }
+    // (b) the node ids along the paths: a few dwords per thread, in registers
+    constexpr int PER_PATH = SCAN2_THREADS / TILE2_MAX;                  // threads per path (NM8: 7 paths use them)
     constexpr int LID_LOADS = ((GFAL_MAX_STEPS + 8) / 2 + PER_PATH - 1) / PER_PATH;     // nm / 2 dwords
     const int my_p = tid / PER_PATH, my_q = tid % PER_PATH;
     const bool have_p = my_p < tv.tile_paths;
-    uint32_t sreg[STEP_LOADS], lreg[LID_LOADS];
+    uint32_t lreg[LID_LOADS];
     {
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(
-            a.images + (size_t)(tv.path0 + (have_p ? my_p : 0)) * a.L.total + a.L.step_at());
         const uint32_t *lsrc = reinterpret_cast<const uint32_t *>(
             a.lids + (size_t)(tv.path0 + (have_p ? my_p : 0)) * nm);
-#pragma unroll
-        for (int k = 0; k < STEP_LOADS; ++k) {
-            const int o = my_q + k * PER_PATH;
-            sreg[k] = (have_p && o < nm) ? src[o] : 0xFFFFFFFFu;
-        }
 #pragma unroll
         for (int k = 0; k < LID_LOADS; ++k) {
             const int o = my_q + k * PER_PATH;
@@ -1884,12 +1890,6 @@ __global__ __launch_bounds__(SCAN2_THREADS, SCAN2_WAVES_PER_SIMD) void k_scan2(S
     if (tid < 16) misc[tid] = 0;               // [0] entries, [1] overflow flag, [2 + t] common prefixes
     __syncthreads();
     if (have_p) {
-        uint32_t *dst = reinterpret_cast<uint32_t *>(steps + (size_t)my_p * 2 * nm);
-#pragma unroll
-        for (int k = 0; k < STEP_LOADS; ++k) {
-            const int o = my_q + k * PER_PATH;
-            if (o < nm) dst[o] = sreg[k];
-        }
         // which tile paths carry each node (the filter of src/eval.cpp:81-91 as a bit test)
 #pragma unroll
         for (int k = 0; k < LID_LOADS; ++k) {
