@@ -27,7 +27,7 @@ SCORER_SO = os.path.join(CSRC, "libgfalign_scorer.so")
 CLI_BIN = os.path.join(CSRC, "gfalign")
 
 SCORER_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread"]
-CLI_FLAGS = ["-O2", "-std=c++17", "-Wall", "-Wextra", "-pthread"]
+CLI_FLAGS = ["-O3", "-std=c++17", "-Wall", "-Wextra", "-pthread"]
 
 
 def _hipcc():

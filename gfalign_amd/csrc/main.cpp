@@ -707,6 +707,7 @@ int main(int argc, char **argv)
         so.return_all_paths = o.return_all_paths != 0;
         if (const char *k = getenv("GFALIGN_SPECULATE")) so.speculate = (size_t)std::max(1, atoi(k));
         if (const char *k = getenv("GFALIGN_PREFETCH")) so.prefetch = atoi(k) != 0;
+        if (const char *k = getenv("GFALIGN_INCREMENTAL")) so.incremental = atoi(k) != 0;
         const double t_open = gfal::now_s();
         Search search(g, scorer, so, std::cout);
         int rc = search.run();
@@ -720,10 +721,12 @@ int main(int argc, char **argv)
             fprintf(stderr, "%zu devices, per-path counters summed %s\n", scorer.n_shards(),
                     scorer.uses_rccl() ? "by an RCCL all-reduce" : "on the host");
         if (verbose_flag)
-            fprintf(stderr, "scored %llu candidate paths in %llu batches (%llu pairs took the exact DP); batch in "
+            fprintf(stderr, "scored %llu candidate paths in %llu batches, %llu of them in full and the rest from "
+                            "their parents (%llu pairs took the exact DP); batch in "
                             "flight held what was needed next %llu times, not %llu times\n",
                     (unsigned long long)search.scored_paths(),
-                    (unsigned long long)search.batches(), (unsigned long long)scorer.dp_pairs(),
+                    (unsigned long long)search.batches(), (unsigned long long)search.scored_in_full(),
+                    (unsigned long long)scorer.dp_pairs(),
                     (unsigned long long)search.prefetch_hits(), (unsigned long long)search.prefetch_misses());
         return rc;
     }

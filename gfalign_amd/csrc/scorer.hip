@@ -2879,6 +2879,589 @@ __global__ void k_fill_i32(int32_t *p, long long n, int32_t v)
 }  // namespace
 
 // --------------------------------------------------------------------------
+// Search mode: a candidate scored from its parent (gfal_group_score_children).
+//
+// `gfalign search` only ever scores `parent + one step` (reference
+// src/eval.cpp:146-162), and with the filter on (src/eval.cpp:81-91) the
+// counters of src/eval.cpp:92-98 split into
+//     Pass(A)  alignments all of whose nodes are on A                 (bad + good)
+//     G1(A)    of those: zero-step ones and contiguous subpaths of A, either
+//              strand                                     (good without the DP)
+//     G2(A)    of the rest: start-overhang pairs the exact DP accepts
+// For A' = A + [s] with len(A) >= the longest alignment (so "m > n" never holds):
+//     Pass(A') = Pass(A) + #{B : node(s) in B, nodes(B) on A'}   if node(s) is new
+//     G1(A')   = G1(A) + sum over M in (Lmax, Mmax] of mult(W_M) + mult(rc(W_M))
+//                (once if W_M is its own reverse complement); W_M = the last M steps
+//                of A', Lmax = the longest W_M that already occurs in A, either
+//                strand, mult = how many alignments have exactly that content
+//     G2(A')   recomputed: its candidates all contain the node of A'[0]
+// (tests/incr_model.py fuzzes these identities against the plain rule).  So a
+// child costs a walk over the alignments that contain its new node and its first
+// node -- two inverted lists -- and at most Mmax table lookups, instead of a scan
+// over all alignments.  The exact DP and everything around it (k_prep images,
+// worklist sort, k_dp_*) are the batch pipeline's own.
+//
+// Scored paths live in a device-side store (caller-managed slots: steps, Pass,
+// G1); a batch names every child as (parent, step), the parent being a slot or
+// an earlier child of the same batch.
+// --------------------------------------------------------------------------
+constexpr int STORE_STRIDE = GFAL_MAX_STEPS;     // int32 steps per store slot
+constexpr int CHILD_MAX_DEPTH = 64;              // in-batch ancestors of one child
+constexpr int CHILD_THREADS = 256;
+constexpr uint32_t CT_EMPTY = 0xFFFFFFFFu;
+constexpr uint32_t ST_BAD_CHILD = 8u;            // status flag: bad parent reference / slot / length
+
+struct ChildIndex {              // built once per scorer, on the device
+    const uint32_t *inv_off;     // [n_local * N_CLASSES + 1] (node, DP length class) -> range of inv_slot
+    const uint32_t *inv_slot;    // lanes (item * 64 + lane) whose alignment has the node
+    const uint32_t *ct_key;      // content table: representative lane or CT_EMPTY
+    const uint32_t *ct_hash;     // its whash
+    const uint32_t *ct_mult;     // alignments with exactly that content (weights summed)
+    uint32_t ct_mask;
+};
+
+__device__ __forceinline__ bool lane_same_content(const Items &items, uint32_t x, uint32_t y)
+{
+    const uint32_t ix = x >> 6, iy = y >> 6;
+    const int m = items.len[ix];
+    if (m != (int)items.len[iy]) return false;
+    const uint16_t *px = items.steps + (size_t)items.base[ix] * WAVE + (x & 63u);
+    const uint16_t *py = items.steps + (size_t)items.base[iy] * WAVE + (y & 63u);
+    for (int t = 0; t < m; ++t)
+        if (px[(size_t)t * WAVE] != py[(size_t)t * WAVE]) return false;
+    return true;
+}
+
+// one thread per lane: distinct nodes of its alignment -> cnt[node]++ (fill == NULL)
+// or inv_slot[cursor[node]++] = lane
+__global__ void k_inv_build(Items items, const int32_t *__restrict__ slot_orig, uint32_t n_slots,
+                            uint32_t *__restrict__ cnt_or_cursor, uint32_t *__restrict__ fill)
+{
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= n_slots || slot_orig[slot] < 0) return;
+    const uint32_t it = slot >> 6;
+    const int m = items.len[it];
+    const uint16_t *bp = items.steps + (size_t)items.base[it] * WAVE + (slot & 63u);
+    for (int t = 0; t < m; ++t) {
+        const uint32_t node = (uint32_t)bp[(size_t)t * WAVE] >> 1;
+        bool seen = false;
+        for (int u = 0; u < t && !seen; ++u) seen = ((uint32_t)bp[(size_t)u * WAVE] >> 1) == node;
+        if (seen) continue;
+        const uint32_t at = atomicAdd(&cnt_or_cursor[node * N_CLASSES + (uint32_t)length_class(m)], 1u);
+        if (fill) fill[at] = slot;
+    }
+}
+
+// exclusive scan of cnt[0 .. n) -> off[0 .. n], cursor = off (one workgroup)
+__global__ __launch_bounds__(1024) void k_inv_scan(const uint32_t *__restrict__ cnt, int n,
+                                                   uint32_t *__restrict__ off, uint32_t *__restrict__ cursor)
+{
+    __shared__ uint32_t part[1024];
+    const int tid = threadIdx.x, per = (n + 1023) / 1024;
+    const int lo = min(tid * per, n), hi = min(lo + per, n);
+    uint32_t sum = 0;
+    for (int i = lo; i < hi; ++i) sum += cnt[i];
+    part[tid] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const uint32_t v = tid >= o ? part[tid - o] : 0u;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[tid] - sum;
+    for (int i = lo; i < hi; ++i) {
+        off[i] = run;
+        cursor[i] = run;
+        run += cnt[i];
+    }
+    if (tid == 1023) off[n] = part[1023];
+}
+
+// one thread per lane: enter its alignment into the content table
+__global__ void k_ct_build(Items items, const int32_t *__restrict__ slot_orig, uint32_t n_slots,
+                           const uint32_t *__restrict__ item_hash, uint32_t *__restrict__ key,
+                           uint32_t *__restrict__ hash, uint32_t *__restrict__ mult, uint32_t mask)
+{
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= n_slots || slot_orig[slot] < 0) return;
+    const uint32_t h = item_hash[slot];
+    const uint32_t w = items.weight ? items.weight[slot] : 1u;
+    uint32_t idx = h & mask;
+    while (true) {
+        const uint32_t prev = atomicCAS(&key[idx], CT_EMPTY, slot);
+        if (prev == CT_EMPTY) {
+            hash[idx] = h;
+            atomicAdd(&mult[idx], w);
+            return;
+        }
+        if (item_hash[prev] == h && lane_same_content(items, prev, slot)) {
+            atomicAdd(&mult[idx], w);
+            return;
+        }
+        idx = (idx + 1u) & mask;
+    }
+}
+
+struct ChildBatch {
+    const int32_t *parent;   // [n] >= 0: store slot; < 0: ~index of an earlier child of the batch
+    const int32_t *step;     // [n] the appended step (caller's packed code)
+    const int32_t *slot;     // [n] where to keep the child, or -1
+    int n;
+    int32_t *st_steps;       // the store
+    int32_t *st_len;
+    uint32_t *st_pass, *st_g1;
+    int64_t st_cap;
+    int32_t *root, *depth;   // [n] scratch: stored ancestor, steps beyond it
+    uint32_t *dpass, *dg1;   // [n] scratch: the child's own deltas
+};
+
+// lengths and offsets of the batch's paths (one workgroup)
+__global__ __launch_bounds__(1024) void k_child_len(ChildBatch b, int max_len, int min_parent_len,
+                                                    int32_t *__restrict__ path_off)
+{
+    __shared__ uint32_t part[1024];
+    const int tid = threadIdx.x, per = (b.n + 1023) / 1024;
+    const int lo = min(tid * per, b.n), hi = min(lo + per, b.n);
+    uint32_t sum = 0;
+    for (int i = lo; i < hi; ++i) {
+        int j = i, d = 1;
+        bool good = true;
+        while (b.parent[j] < 0) {
+            const int up = ~b.parent[j];
+            if (up >= j || d >= CHILD_MAX_DEPTH) {
+                good = false;
+                break;
+            }
+            j = up;
+            ++d;
+        }
+        int r = good ? b.parent[j] : 0;
+        if (r < 0 || r >= b.st_cap) {
+            good = false;
+            r = 0;
+        }
+        int L = 1;
+        if (good) {
+            const int l0 = b.st_len[r];
+            L = l0 + d;
+            if (l0 < 1 || l0 < min_parent_len || L > max_len || L > GFAL_MAX_STEPS) good = false;
+        }
+        if (b.slot[i] >= b.st_cap) good = false;
+        if (!good) {       // root = -1 marks it; k_child_resolve raises ST_BAD_CHILD
+            L = 1;
+            d = 1;
+        }
+        b.root[i] = good ? r : -1;
+        b.depth[i] = d;
+        path_off[i + 1] = L;
+        sum += (uint32_t)L;
+    }
+    part[tid] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const uint32_t v = tid >= o ? part[tid - o] : 0u;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[tid] - sum;
+    if (tid == 0) path_off[0] = 0;
+    for (int i = lo; i < hi; ++i) {
+        run += (uint32_t)path_off[i + 1];
+        path_off[i + 1] = (int32_t)run;
+    }
+}
+
+// the batch's paths, written out (and into their store slots): one workgroup per child
+__global__ __launch_bounds__(256) void k_child_copy(ChildBatch b, const int32_t *__restrict__ path_off,
+                                                    int32_t *__restrict__ path_steps)
+{
+    const int i = blockIdx.x, tid = threadIdx.x;
+    const int off = path_off[i], L = path_off[i + 1] - off;
+    const int r = b.root[i], d = b.depth[i];
+    const int slot = r >= 0 ? b.slot[i] : -1;
+    int32_t *keep = slot >= 0 ? b.st_steps + (size_t)slot * STORE_STRIDE : nullptr;
+    if (tid == 0) {
+        b.dpass[i] = 0;
+        b.dg1[i] = 0;
+    }
+    if (r < 0) {           // rejected by k_child_len: a one-step dummy
+        if (tid == 0) path_steps[off] = 0;
+        return;
+    }
+    const int l0 = L - d;
+    const int32_t *src = b.st_steps + (size_t)r * STORE_STRIDE;
+    for (int k = tid; k < l0; k += 256) {
+        const int32_t v = src[k];
+        path_steps[off + k] = v;
+        if (keep) keep[k] = v;
+    }
+    if (tid == 0) {
+        int j = i;
+        for (int k = d - 1; k >= 0; --k) {
+            const int32_t v = b.step[j];
+            path_steps[off + l0 + k] = v;
+            if (keep) keep[l0 + k] = v;
+            j = ~b.parent[j];
+        }
+        if (slot >= 0) b.st_len[slot] = L;
+    }
+}
+
+struct ChildArgs {
+    Items items;
+    ChildIndex ix;
+    const uint16_t *images;
+    ImageLayout L;
+    const uint16_t *lids;      // [n_paths][nm] local node id per path step (k_prep)
+    const int32_t *order;      // image slot -> child index
+    int n_paths, max_aln_len;
+    uint32_t *dpass, *dg1;     // by child index
+    uint32_t *counts;          // by image slot: bad | good | unaligned
+    unsigned long long *worklist;
+    unsigned long long *wl_count;
+    uint32_t wl_capacity;
+    uint32_t *wl_hist;
+    uint32_t *status;
+};
+
+// multiplicity of the content  W[t] = step[start + dir * t] ^ flip,  t < M
+__device__ __forceinline__ uint32_t ct_lookup(const ChildArgs &a, uint32_t h, int M, const uint16_t *step,
+                                              int start, int dir, uint32_t flip)
+{
+    uint32_t idx = h & a.ix.ct_mask;
+    while (true) {
+        const uint32_t key = a.ix.ct_key[idx];
+        if (key == CT_EMPTY) return 0u;
+        if (a.ix.ct_hash[idx] == h) {
+            const uint32_t it = key >> 6;
+            if ((int)a.items.len[it] == M) {
+                const uint16_t *bp = a.items.steps + (size_t)a.items.base[it] * WAVE + (key & 63u);
+                bool eq = true;
+                for (int t = 0; t < M && eq; ++t)
+                    eq = (uint32_t)bp[(size_t)t * WAVE] == ((uint32_t)step[start + dir * t] ^ flip);
+                if (eq) return a.ix.ct_mult[idx];
+            }
+        }
+        idx = (idx + 1u) & a.ix.ct_mask;
+    }
+}
+
+// grid (children, chunks): chunk 0 finds the child's new windows; every chunk takes
+// its share of the two inverted lists.  A lane holds one alignment of a list at a
+// time: its first step in a register, the others (up to 33 steps) as pair dwords in
+// the lane's own LDS column, so the divergent per-lane loops below read LDS, not HBM.
+constexpr int CHILD_WAVES = CHILD_THREADS / WAVE;
+constexpr int CHILD_STAGE_PAIRS = 16;
+constexpr int CHILD_WL_BUF = 4096;             // worklist entries a workgroup gathers before it appends them
+constexpr int CHILD_STATIC_LDS = CHILD_WAVES * CHILD_STAGE_PAIRS * WAVE * 4 + CHILD_WL_BUF * 8 + 256;
+
+template <bool W>
+__global__ __launch_bounds__(CHILD_THREADS) void k_child(ChildArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+    __shared__ uint32_t red[4];     // Lmax | node seen before
+    __shared__ uint32_t stage[CHILD_WAVES][CHILD_STAGE_PAIRS][WAVE];
+    __shared__ unsigned long long wl_buf[CHILD_WL_BUF];
+    __shared__ uint32_t wl_n, wl_cls[N_CLASSES], wl_base[2];
+    uint16_t *img = smem;
+    uint16_t *lid = smem + a.L.total;
+    const int q = blockIdx.x, chunk = blockIdx.y, n_chunks = gridDim.y;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+    {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(a.images + (size_t)q * a.L.total);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(img);
+        for (int i = tid; i < a.L.total / 2; i += CHILD_THREADS) dst[i] = src[i];
+        const uint32_t *lsrc = reinterpret_cast<const uint32_t *>(a.lids + (size_t)q * a.L.nm);
+        uint32_t *ldst = reinterpret_cast<uint32_t *>(lid);
+        for (int i = tid; i < a.L.nm / 2; i += CHILD_THREADS) ldst[i] = lsrc[i];
+        if (tid < 4) red[tid] = 0;
+        if (tid < N_CLASSES) wl_cls[tid] = 0;
+        if (tid == 0) wl_n = 0;
+    }
+    __syncthreads();
+    const uint32_t *first32 = reinterpret_cast<const uint32_t *>(img + a.L.first_at());
+    const uint32_t *next = reinterpret_cast<const uint32_t *>(img + a.L.next_at());
+    const uint32_t *step32 = reinterpret_cast<const uint32_t *>(img + a.L.step_at());
+    const uint32_t *lid32 = reinterpret_cast<const uint32_t *>(lid);
+    const int n = img[a.L.len_at()];
+    if (n < 2) return;                       // (rejected child: nothing to add)
+    const int child = a.order[q];
+    const uint32_t s = lds_u16(step32, (uint32_t)(n - 1)), s_lid = lds_u16(lid32, (uint32_t)(n - 1));
+    const uint32_t a0 = lds_u16(step32, 0u), a0_lid = lds_u16(lid32, 0u);
+    const int cap = min(a.max_aln_len, n);   // longest window that can be an alignment
+    auto stepA = [&](int k) -> uint32_t { return lds_u16(step32, (uint32_t)k); };
+    auto on_path = [&](uint32_t code) -> bool { return lds_u16(first32, code >> 1) != ENT_NONE; };
+
+    // has the new node been on the path before; how long a suffix window is old
+    {
+        uint32_t my_old = 0, my_l = 0;
+        for (int p = tid; p < n - 1; p += CHILD_THREADS) {
+            if (lds_u16(lid32, (uint32_t)p) == s_lid) my_old = 1;
+            if (chunk == 0 && s != STEP_NOMATCH) {
+                const uint32_t c = stepA(p);
+                if (c == s) {
+                    int l = 1;
+                    while (l < cap && p - l >= 0 && stepA(p - l) == stepA(n - 1 - l)) ++l;
+                    my_l = max(my_l, (uint32_t)l);
+                } else if (c == (s ^ 1u)) {
+                    int l = 1;
+                    while (l < cap && p + l < n - 1 && stepA(p + l) == (stepA(n - 1 - l) ^ 1u)) ++l;
+                    my_l = max(my_l, (uint32_t)l);
+                }
+            }
+        }
+        if (my_l) atomicMax(&red[0], my_l);
+        if (my_old) atomicOr(&red[1], 1u);
+    }
+    __syncthreads();
+    const int lmax = (int)red[0];
+    const bool is_new = red[1] == 0u && s_lid != ENT_NONE;
+
+    uint32_t hits = 0, newpass = 0, ncand = 0;
+    if (chunk == 0 && s != STEP_NOMATCH) {
+        const uint16_t *step = img + a.L.step_at();
+        for (int M = lmax + 1 + tid; M <= cap; M += CHILD_THREADS) {
+            uint32_t hf = whash_init(M), hr = whash_init(M);
+            bool ok = true, pal = true;
+            for (int t = 0; t < M; ++t) {
+                const uint32_t cf = stepA(n - M + t);
+                const uint32_t cr = stepA(n - 1 - t) ^ 1u;
+                ok &= cf != STEP_NOMATCH;
+                pal &= cf == cr;
+                hf = whash_step(hf, cf);
+                hr = whash_step(hr, cr);
+            }
+            if (!ok) continue;
+            hits += ct_lookup(a, whash_final(hf), M, step, n - M, 1, 0u);
+            if (!pal) hits += ct_lookup(a, whash_final(hr), M, step, n - 1, -1, 1u);
+        }
+    }
+
+    // one alignment of an inverted list per lane
+    uint32_t (*mine)[WAVE] = stage[tid >> 6];
+    uint32_t b0 = 0;
+    const uint16_t *bp = nullptr;
+    bool staged = false;
+    auto load_B = [&](uint32_t slot) -> int {
+        const uint4 h = a.items.hdr[slot >> 6];          // base, pbase, common, len
+        const int m = (int)h.w;
+        bp = a.items.steps + (size_t)h.x * WAVE + (slot & 63u);
+        b0 = bp[0];
+        staged = m <= 2 * CHILD_STAGE_PAIRS + 1;
+        if (staged) {
+            const uint32_t *pp = a.items.pairs + (size_t)h.y * WAVE + (slot & 63u);
+            for (int j = 0; j < m / 2; ++j) mine[j][lane] = pp[(size_t)j * WAVE];
+        }
+        return m;
+    };
+    auto B = [&](int t) -> uint32_t {
+        if (t == 0) return b0;
+        if (staged) return (mine[(t - 1) >> 1][lane] >> (((t - 1) & 1) * 16)) & 0xFFFFu;
+        return bp[(size_t)t * WAVE];
+    };
+    const uint32_t g = (uint32_t)chunk * CHILD_THREADS + (uint32_t)tid;
+    const uint32_t stride = (uint32_t)n_chunks * CHILD_THREADS;
+    if (is_new) {      // the alignments that carry the new node: which of them pass the filter now
+        const uint32_t lo = a.ix.inv_off[s_lid * N_CLASSES], hi = a.ix.inv_off[(s_lid + 1u) * N_CLASSES];
+        for (uint32_t e = lo + g; e < hi; e += stride) {
+            const uint32_t slot = a.ix.inv_slot[e];
+            const int m = load_B(slot);
+            bool pass = true;
+            for (int t = 0; t < m && pass; ++t) pass = on_path(B(t));
+            if (pass) newpass += W ? a.items.weight[slot] : 1u;
+        }
+    }
+    // start-overhang candidates: alignments that carry the path's first node, one DP
+    // length class after the other (the worklist sort wants runs of one class).  They
+    // are gathered in LDS and leave the workgroup with ONE atomic on the list cursor
+    // (an atomic per wave and round on that one word was 90 % of this kernel).
+    auto flush = [&]() {            // (every thread of the workgroup calls it)
+        __syncthreads();
+        const uint32_t cnt = wl_n;
+        if (cnt != 0u) {
+            if (tid == 0) {
+                const unsigned long long base = atomicAdd(a.wl_count, (unsigned long long)cnt);
+                wl_base[0] = (uint32_t)base;
+                wl_base[1] = (uint32_t)(base >> 32);
+                for (int c = 0; c < N_CLASSES; ++c)
+                    if (wl_cls[c]) {
+                        atomicAdd(&a.wl_hist[(uint32_t)c * (uint32_t)a.n_paths + (uint32_t)q], wl_cls[c]);
+                        wl_cls[c] = 0;
+                    }
+            }
+            __syncthreads();
+            const unsigned long long base = ((unsigned long long)wl_base[1] << 32) | wl_base[0];
+            bool over = false;
+            for (uint32_t i = (uint32_t)tid; i < cnt; i += CHILD_THREADS) {
+                if (base + i < a.wl_capacity) a.worklist[base + i] = wl_buf[i];
+                else over = true;
+            }
+            if (over) atomicOr(a.status, ST_DP_OVERFLOW);
+            __syncthreads();
+            if (tid == 0) wl_n = 0;
+        }
+        __syncthreads();
+    };
+    if (a0 != STEP_NOMATCH && a0_lid != ENT_NONE) {
+        for (int cls = 0; cls < N_CLASSES; ++cls) {
+            const uint32_t lo = a.ix.inv_off[a0_lid * N_CLASSES + (uint32_t)cls];
+            const uint32_t hi = a.ix.inv_off[a0_lid * N_CLASSES + (uint32_t)cls + 1u];
+            for (uint32_t e0 = lo + (uint32_t)chunk * CHILD_THREADS; e0 < hi; e0 += stride) {
+                const uint32_t e = e0 + (uint32_t)tid;
+                bool fw = false, rc = false;
+                uint32_t slot = 0;
+                int m = 0;
+                if (e < hi) {
+                    slot = a.ix.inv_slot[e];
+                    m = load_B(slot);
+                    if (m >= 2 && m <= n) {
+                        // a proper suffix of B (of rc(B)) equals a prefix of the path
+                        for (int t = 1; t < m && !fw; ++t)
+                            if (B(t) == a0) {
+                                bool eq = true;
+                                for (int k = 1; k < m - t && eq; ++k) eq = B(t + k) == stepA(k);
+                                fw = eq;
+                            }
+                        for (int t = 0; t + 1 < m && !rc; ++t)
+                            if ((B(t) ^ 1u) == a0) {
+                                bool eq = true;
+                                for (int k = 1; k <= t && eq; ++k) eq = (B(t - k) ^ 1u) == stepA(k);
+                                rc = eq;
+                            }
+                    }
+                }
+                if (fw || rc) {
+                    bool pass = true;      // the filter (src/eval.cpp:81-91)
+                    for (int t = 0; t < m && pass; ++t) pass = on_path(B(t));
+                    bool found = false;    // a subpath on either strand is good without the DP
+                    if (pass) {
+                        uint32_t ent = lds_u16(first32, b0 >> 1);
+                        while ((ent & 0x7C00u) == 0u && !found) {
+                            const int pos = (int)(ent & ENT_POS);
+                            const bool neg = (ent & ENT_NEG) != 0u;
+                            bool eq = false;
+                            if (neg == ((b0 & 1u) != 0u)) {
+                                if (pos + m <= n) {
+                                    eq = true;
+                                    for (int t = 1; t < m && eq; ++t) eq = stepA(pos + t) == B(t);
+                                }
+                            } else if (pos >= m - 1) {
+                                eq = true;
+                                for (int t = 1; t < m && eq; ++t) eq = stepA(pos - t) == (B(t) ^ 1u);
+                            }
+                            found = eq;
+                            ent = next[pos];
+                        }
+                    }
+                    if (!pass || found) fw = rc = false;
+                }
+                const bool want = fw || rc;
+                const lanemask wm = WAVE_MASK(want);
+                if (wm != 0ull) {
+                    const int leader = __builtin_ctzll(wm);
+                    uint32_t at = 0;
+                    if (lane == leader) {
+                        const uint32_t cnt = (uint32_t)__builtin_popcountll(wm);
+                        at = atomicAdd(&wl_n, cnt);
+                        atomicAdd(&wl_cls[cls], cnt);
+                    }
+                    at = (uint32_t)__builtin_amdgcn_readlane((int)at, leader);
+                    if (want) {
+                        wl_buf[at + lanes_below(wm, lane)] = (fw ? WL_FW : 0ull) | (rc ? WL_RC : 0ull) |
+                                                              ((unsigned long long)(uint32_t)q << 32) | slot;
+                        ncand += W ? a.items.weight[slot] : 1u;
+                    }
+                }
+                __syncthreads();
+                if (wl_n > (uint32_t)(CHILD_WL_BUF - CHILD_THREADS)) flush();     // (the same for every thread)
+            }
+        }
+    }
+    flush();
+    // the workgroup's sums: the DP kernels add every candidate to good or to bad, so
+    // the candidates leave `bad` here (k_child_resolve put Pass' - G1' there)
+    for (int o = 32; o > 0; o >>= 1) {
+        hits += __shfl_down(hits, o, WAVE);
+        newpass += __shfl_down(newpass, o, WAVE);
+        ncand += __shfl_down(ncand, o, WAVE);
+    }
+    if (lane == 0) {
+        if (hits) atomicAdd(&a.dg1[child], hits);
+        if (newpass) atomicAdd(&a.dpass[child], newpass);
+        if (ncand) atomicSub(&a.counts[q], ncand);
+    }
+}
+
+// Pass / G1 of every child from its stored ancestor's and the deltas on the way;
+// into the counters (by image slot) and into the child's store slot
+__global__ void k_child_resolve(ChildBatch b, const int32_t *__restrict__ order, int n_paths,
+                                uint32_t n_empty, uint32_t *__restrict__ counts,
+                                uint32_t *__restrict__ status)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_paths) return;
+    const int i = order[q];
+    const int r = b.root[i];
+    if (r < 0) {           // bad parent reference, slot or length (k_child_len)
+        atomicOr(status, ST_BAD_CHILD);
+        return;
+    }
+    uint32_t pass = b.st_pass[r], g1 = b.st_g1[r];
+    int j = i;
+    for (int k = b.depth[i]; k > 0; --k) {
+        pass += b.dpass[j];
+        g1 += b.dg1[j];
+        j = ~b.parent[j];
+    }
+    atomicAdd(&counts[q], pass - g1);
+    atomicAdd(&counts[n_paths + q], g1 - n_empty);
+    const int slot = b.slot[i];
+    if (slot >= 0) {
+        b.st_pass[slot] = pass;
+        b.st_g1[slot] = g1;
+    }
+}
+
+// full scoring with the store: good-without-DP per image slot, taken between the
+// scan and the DP kernels ...
+__global__ void k_store_snapshot(const uint32_t *__restrict__ counts, int n_paths, uint32_t *__restrict__ g1_tmp)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n_paths) g1_tmp[q] = counts[n_paths + q];
+}
+
+// ... and the paths with their Pass / G1 into their slots when the call is done
+__global__ __launch_bounds__(256) void k_store_paths(const int32_t *__restrict__ path_off,
+                                                     const int32_t *__restrict__ path_steps,
+                                                     const int32_t *__restrict__ order, int n_paths,
+                                                     const uint32_t *__restrict__ counts,
+                                                     const uint32_t *__restrict__ g1_tmp,
+                                                     const int32_t *__restrict__ slots, int32_t *st_steps,
+                                                     int32_t *st_len, uint32_t *st_pass, uint32_t *st_g1,
+                                                     int64_t st_cap, uint32_t *__restrict__ status)
+{
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const int i = order[q];
+    const int slot = slots[i];
+    if (slot < 0) return;
+    if (slot >= st_cap) {
+        if (tid == 0) atomicOr(status, ST_BAD_CHILD);
+        return;
+    }
+    const int off = path_off[i], L = path_off[i + 1] - off;
+    if (L < 1 || L > STORE_STRIDE) return;
+    int32_t *keep = st_steps + (size_t)slot * STORE_STRIDE;
+    for (int k = tid; k < L; k += 256) keep[k] = path_steps[off + k];
+    if (tid == 0) {
+        st_len[slot] = L;
+        st_pass[slot] = counts[q] + counts[n_paths + q];
+        st_g1[slot] = g1_tmp[q];
+    }
+}
+
+// --------------------------------------------------------------------------
 // host side
 // --------------------------------------------------------------------------
 struct gfal_scorer {
@@ -2953,6 +3536,20 @@ struct gfal_scorer {
     hipStream_t dp_stream[3] = {nullptr, nullptr, nullptr};
     hipEvent_t dp_fork = nullptr, dp_join[3] = {nullptr, nullptr, nullptr};
 
+    // search mode (gfal_group_score_children): inverted lists by node and the content
+    // table, built on the device at the first use; the path store; per-call scratch
+    bool child_index = false;
+    uint32_t *d_inv_off = nullptr, *d_inv_slot = nullptr;
+    uint32_t *d_ct_key = nullptr, *d_ct_hash = nullptr, *d_ct_mult = nullptr;
+    uint32_t ct_mask = 0;
+    int32_t *d_st_steps = nullptr, *d_st_len = nullptr;
+    uint32_t *d_st_pass = nullptr, *d_st_g1 = nullptr;
+    int64_t st_cap = 0;
+    int32_t *d_child_in = nullptr;     // [parent | step | slot] of a children batch, or the slots of a stored one
+    int32_t *d_child_tmp = nullptr;    // root | depth | dpass | dg1   (or the G1 snapshot)
+    size_t child_in_cap = 0, child_tmp_cap = 0;
+    int64_t n_children_calls = 0;
+
     int64_t n_score_calls = 0, n_device_passes = 0, n_overflow_reruns = 0;
     // status words of the last blocking call (they came back with its counters):
     // gfal_scorer_get_info then needs no device round trip (a search asks after every batch)
@@ -3021,7 +3618,9 @@ void free_scorer(gfal_scorer *s)
                     s->d_item_len,   s->d_slot_orig, s->d_status,     s->d_worklist,
                     s->d_worklist_sorted, s->d_wl_bins,
                     s->d_rows,       s->d_images,    s->d_path_off,   s->d_path_steps,
-                    s->d_counts};
+                    s->d_counts,     s->d_inv_off,   s->d_inv_slot,   s->d_ct_key,
+                    s->d_ct_hash,    s->d_ct_mult,   s->d_st_steps,   s->d_st_len,
+                    s->d_st_pass,    s->d_st_g1,     s->d_child_in,   s->d_child_tmp};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (s->graph_exec) (void)hipGraphExecDestroy(s->graph_exec);
@@ -3826,10 +4425,19 @@ static int ensure_call_buffers(gfal_scorer *s, int32_t n_paths, const ImageLayou
     return GFAL_OK;
 }
 
+// What a call does besides scoring (search mode, see k_child).
+struct ExtraCtx {
+    int mode = 0;                    // 1: keep the batch's paths in the store; 2: children batch
+    const int32_t *d_slots = nullptr;   // mode 1: [n_paths] store slot per path or -1
+    uint32_t *d_g1_tmp = nullptr;       // mode 1: [n_paths] scratch
+    ChildBatch batch;                // mode 2
+};
+
 static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
                              const int32_t *d_path_steps, int32_t n_paths,
                              int64_t total_steps, int32_t max_path_len, int filter,
-                             uint32_t *d_counts, void *hip_stream, uint32_t *status_copy)
+                             uint32_t *d_counts, void *hip_stream, uint32_t *status_copy,
+                             const ExtraCtx *cx = nullptr)
 {
     if (!s || n_paths < 0 || total_steps < 0) return GFAL_E_ARG;
     if (n_paths == 0) return GFAL_OK;
@@ -3942,8 +4550,47 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
         if (!chain_fits || s->scan_mode == 2) n_segs2 = (int)s->segs.size();
         if (n_segs2 == 0 && !chain_fits) return GFAL_E_RANGE;
         const int item_lo_chain = n_segs2 > 0 ? (int)s->segs[(size_t)n_segs2 - 1].item_hi : 0;
+        const bool children = cx && cx->mode == 2;
+        if (children) {
+            // every child from its parent: the two inverted lists and the content table
+            // instead of a scan over all alignments
+            ChildArgs c;
+            c.items = items;
+            c.ix = ChildIndex{s->d_inv_off, s->d_inv_slot, s->d_ct_key, s->d_ct_hash, s->d_ct_mult, s->ct_mask};
+            c.images = s->d_images;
+            c.L = L;
+            c.lids = s->d_lids;
+            c.order = s->d_order;
+            c.n_paths = n_paths;
+            c.max_aln_len = s->max_aln_len;
+            c.dpass = cx->batch.dpass;
+            c.dg1 = cx->batch.dg1;
+            c.counts = d_counts;
+            c.worklist = s->d_worklist;
+            c.wl_count = wl_count;
+            c.wl_capacity = s->wl_capacity;
+            c.wl_hist = d_hist;
+            c.status = s->d_status;
+            int chunks = std::max(1, std::min(32, 4 * s->n_cus / (int)n_paths));
+            if (const char *env = getenv("GFAL_CHILD_CHUNKS")) chunks = std::max(1, atoi(env));
+            const size_t lds_c = img_bytes + (size_t)L.nm * sizeof(uint16_t);
+            if (lds_c > (size_t)LDS_MAX - CHILD_STATIC_LDS) {
+                set_err("%d local nodes exceed the LDS budget of the children kernel", s->n_local);
+                return GFAL_E_RANGE;
+            }
+            if (s->d_item_weight)
+                hipLaunchKernelGGL(k_child<true>, dim3((unsigned)n_paths, (unsigned)chunks), dim3(CHILD_THREADS),
+                                   lds_c, st, c);
+            else
+                hipLaunchKernelGGL(k_child<false>, dim3((unsigned)n_paths, (unsigned)chunks), dim3(CHILD_THREADS),
+                                   lds_c, st, c);
+            HIP_TRY(hipGetLastError());
+            s->last_tile = 1;
+            s->last_grid = (int)n_paths * chunks;
+            s->last_lds = (int)lds_c;
+        }
 
-        if (n_segs2 > 0) {
+        if (n_segs2 > 0 && !children) {
             Scan2Args a2;
             a2.items = items;
             a2.item_hash = s->d_item_hash;
@@ -4023,7 +4670,7 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
         a.status = s->d_status;
         a.item_lo = item_lo_chain;
         const int n_items_chain = s->n_items - item_lo_chain;
-        if (n_items_chain > 0) {
+        if (n_items_chain > 0 && !children) {
             int tile = (int)std::min<size_t>(((size_t)LDS_BUDGET - mask_bytes) / img_bytes,
                                              MAX_TILE);
             tile = std::max(1, std::min(tile, (int)n_paths));
@@ -4065,6 +4712,12 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
             }
             s->last_grid += (int)grid;
         }
+        if (children)
+            hipLaunchKernelGGL(k_child_resolve, dim3(p_blocks), dim3(256), 0, st, cx->batch, s->d_order,
+                               (int)n_paths, s->n_empty, d_counts, s->d_status);
+        if (cx && cx->mode == 1)      // good-without-DP, before the DP kernels add theirs
+            hipLaunchKernelGGL(k_store_snapshot, dim3(p_blocks), dim3(256), 0, st, d_counts, (int)n_paths,
+                               cx->d_g1_tmp);
         if (s->profiling) HIP_TRY(hipEventRecord(ev[2], st));
 
         hipLaunchKernelGGL(k_wl_offsets, dim3(N_CLASSES), dim3(1024), 0, st, d_hist, d_offsets,
@@ -4126,9 +4779,20 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
                 HIP_TRY(hipStreamWaitEvent(st, s->dp_join[i], 0));
             }
         HIP_TRY(hipGetLastError());
-    } else if (s->profiling) {
-        HIP_TRY(hipEventRecord(ev[2], st));
+    } else {
+        // a shard without alignments (zero-step ones at most): the store still follows
+        if (cx && cx->mode == 2)
+            hipLaunchKernelGGL(k_child_resolve, dim3(p_blocks), dim3(256), 0, st, cx->batch, s->d_order,
+                               (int)n_paths, s->n_empty, d_counts, s->d_status);
+        if (cx && cx->mode == 1)
+            hipLaunchKernelGGL(k_store_snapshot, dim3(p_blocks), dim3(256), 0, st, d_counts, (int)n_paths,
+                               cx->d_g1_tmp);
+        if (s->profiling) HIP_TRY(hipEventRecord(ev[2], st));
     }
+    if (cx && cx->mode == 1)
+        hipLaunchKernelGGL(k_store_paths, dim3((unsigned)n_paths), dim3(256), 0, st, d_path_off, d_path_steps,
+                           s->d_order, (int)n_paths, d_counts, cx->d_g1_tmp, cx->d_slots, s->d_st_steps,
+                           s->d_st_len, s->d_st_pass, s->d_st_g1, s->st_cap, s->d_status);
     hipLaunchKernelGGL(k_unpermute, dim3(p_blocks), dim3(256), 0, st, d_counts, s->d_order,
                        (int)n_paths, d_user_counts, s->d_status, status_copy);
     HIP_TRY(hipGetLastError());
@@ -4158,6 +4822,12 @@ static int status_to_code(const gfal_scorer *s, const uint32_t *host)
     if (host[0] & (ST_BAD_LEN | ST_BAD_ID)) {
         set_err("device-side validation failed (status 0x%x)", host[0]);
         return GFAL_E_RANGE;
+    }
+    if (host[0] & ST_BAD_CHILD) {
+        set_err("children batch: a parent reference, a store slot or a path length is invalid "
+                "(parents must be stored or earlier in the batch, at least as long as the longest "
+                "alignment, and the child within the stated maximum)");
+        return GFAL_E_ARG;
     }
     if (host[0] & ST_DP_OVERFLOW) {
         set_err("exact-DP worklist overflow (%llu pairs, capacity %u)",
@@ -4192,12 +4862,17 @@ int gfal_scorer_sync_status(gfal_scorer *s)
 // Blocking-API staging without the wait: paths into the pinned buffer and onto the
 // device, the kernels enqueued on the scorer's stream, counters left in
 // s->d_counts[0 .. 3P) and the status words behind them (gfal_group_score).
+// slots != NULL: the paths are also kept in the store (search mode), slots[p] or -1;
+// they travel behind the steps in the same staging buffer.
 static int score_stage(gfal_scorer *s, const int32_t *path_off, const int32_t *path_steps, int32_t P,
-                       int32_t max_len, int filter)
+                       int32_t max_len, int filter, const int32_t *slots = nullptr)
 {
     const int64_t total = path_off[P];
-    const size_t n_in = (size_t)P + 1 + (size_t)total, n_out = (size_t)3 * P + 4;
+    const size_t n_paths_in = (size_t)P + 1 + (size_t)total;
+    const size_t n_in = n_paths_in + (slots ? (size_t)P : 0), n_out = (size_t)3 * P + 4;
     int rc;
+    if (s->have_last && (n_in > s->path_off_cap || n_out > s->counts_cap))
+        HIP_TRY(hipStreamSynchronize(s->last_stream));
     if ((rc = dev_reserve(&s->d_path_off, &s->path_off_cap, n_in))) return rc;
     if ((rc = dev_reserve(&s->d_counts, &s->counts_cap, n_out))) return rc;
     if ((rc = pinned_reserve(&s->h_in, &s->h_in_cap, n_in))) return rc;
@@ -4205,11 +4880,178 @@ static int score_stage(gfal_scorer *s, const int32_t *path_off, const int32_t *p
     if (path_off != s->h_in) {      // (a re-run stages from this very buffer)
         memcpy(s->h_in, path_off, ((size_t)P + 1) * sizeof(int32_t));
         memcpy(s->h_in + P + 1, path_steps, (size_t)total * sizeof(int32_t));
+        if (slots) memcpy(s->h_in + n_paths_in, slots, (size_t)P * sizeof(int32_t));
     }
     HIP_TRY(hipMemcpyAsync(s->d_path_off, s->h_in, n_in * sizeof(int32_t), hipMemcpyHostToDevice, s->stream));
+    ExtraCtx cx;
+    if (slots) {
+        if (s->have_last && (size_t)P > s->child_tmp_cap) HIP_TRY(hipStreamSynchronize(s->last_stream));
+        if ((rc = dev_reserve(&s->d_child_tmp, &s->child_tmp_cap, (size_t)P))) return rc;
+        cx.mode = 1;
+        cx.d_slots = s->d_path_off + n_paths_in;
+        cx.d_g1_tmp = reinterpret_cast<uint32_t *>(s->d_child_tmp);
+    }
     rc = score_device_impl(s, s->d_path_off, s->d_path_off + P + 1, P, total, max_len, filter, s->d_counts,
-                           s->stream, s->d_counts + (size_t)3 * P);
+                           s->stream, s->d_counts + (size_t)3 * P, slots ? &cx : nullptr);
     s->last_stream = s->stream;
+    s->have_last = true;
+    return rc;
+}
+
+// The search-mode index of a scorer (inverted lists by node, content table),
+// built on the device from the resident items at the first use.
+static int build_child_index(gfal_scorer *s)
+{
+    if (s->child_index) return GFAL_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    const uint32_t n_slots = (uint32_t)s->n_items * WAVE;
+    const int n_loc = std::max(1, (int)s->n_local) * N_CLASSES;      // one list per (node, length class)
+    uint32_t *cnt = nullptr, *cursor = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&cnt), (size_t)(n_loc + 1) * sizeof(uint32_t)));
+    struct Tmp {
+        uint32_t *&a, *&b;
+        ~Tmp()
+        {
+            if (a) (void)hipFree(a);
+            if (b) (void)hipFree(b);
+        }
+    } tmp{cnt, cursor};
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&cursor), (size_t)(n_loc + 1) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_inv_off), (size_t)(n_loc + 1) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_inv_slot),
+                      std::max<size_t>((size_t)s->n_item_u16, 1) * sizeof(uint32_t)));
+    uint32_t slots_pow2 = 1024;
+    while ((uint64_t)slots_pow2 < 2ull * std::max<uint32_t>(n_slots, 1u)) slots_pow2 <<= 1;
+    s->ct_mask = slots_pow2 - 1u;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_ct_key), (size_t)slots_pow2 * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_ct_hash), (size_t)slots_pow2 * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_ct_mult), (size_t)slots_pow2 * sizeof(uint32_t)));
+    hipStream_t st = s->stream;
+    HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)(n_loc + 1) * sizeof(uint32_t), st));
+    HIP_TRY(hipMemsetAsync(s->d_inv_off, 0, (size_t)(n_loc + 1) * sizeof(uint32_t), st));
+    HIP_TRY(hipMemsetAsync(s->d_ct_key, 0xFF, (size_t)slots_pow2 * sizeof(uint32_t), st));
+    HIP_TRY(hipMemsetAsync(s->d_ct_hash, 0, (size_t)slots_pow2 * sizeof(uint32_t), st));
+    HIP_TRY(hipMemsetAsync(s->d_ct_mult, 0, (size_t)slots_pow2 * sizeof(uint32_t), st));
+    if (n_slots > 0) {
+        const Items items{s->d_item_steps, s->d_item_base, s->d_item_len, s->d_item_pairs,
+                          s->d_item_pbase, s->n_items, s->d_item_common, s->d_item_hdr, s->d_item_weight};
+        const unsigned blocks = (n_slots + 255u) / 256u;
+        hipLaunchKernelGGL(k_inv_build, dim3(blocks), dim3(256), 0, st, items, s->d_slot_orig, n_slots, cnt,
+                           (uint32_t *)nullptr);
+        hipLaunchKernelGGL(k_inv_scan, dim3(1), dim3(1024), 0, st, cnt, n_loc, s->d_inv_off, cursor);
+        hipLaunchKernelGGL(k_inv_build, dim3(blocks), dim3(256), 0, st, items, s->d_slot_orig, n_slots, cursor,
+                           s->d_inv_slot);
+        hipLaunchKernelGGL(k_ct_build, dim3(blocks), dim3(256), 0, st, items, s->d_slot_orig, n_slots,
+                           s->d_item_hash, s->d_ct_key, s->d_ct_hash, s->d_ct_mult, s->ct_mask);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_child<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - CHILD_STATIC_LDS));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_child<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - CHILD_STATIC_LDS));
+    s->child_index = true;
+    return GFAL_OK;
+}
+
+// Room for `cap` stored paths (grows, keeps what is there).
+static int store_reserve(gfal_scorer *s, int64_t cap)
+{
+    if (cap <= s->st_cap) return GFAL_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    if (s->have_last) HIP_TRY(hipStreamSynchronize(s->last_stream));
+    int32_t *steps = nullptr, *len = nullptr;
+    uint32_t *pass = nullptr, *g1 = nullptr;
+    const size_t n = (size_t)cap;
+    if (hipMalloc(reinterpret_cast<void **>(&steps), n * STORE_STRIDE * sizeof(int32_t)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&len), n * sizeof(int32_t)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&pass), n * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&g1), n * sizeof(uint32_t)) != hipSuccess) {
+        for (void *b : {(void *)steps, (void *)len, (void *)pass, (void *)g1})
+            if (b) (void)hipFree(b);
+        (void)hipGetLastError();
+        set_err("path store: cannot allocate %lld slots", (long long)cap);
+        return GFAL_E_NOMEM;
+    }
+    HIP_TRY(hipMemset(len, 0, n * sizeof(int32_t)));
+    if (s->st_cap > 0) {
+        const size_t o = (size_t)s->st_cap;
+        HIP_TRY(hipMemcpy(steps, s->d_st_steps, o * STORE_STRIDE * sizeof(int32_t), hipMemcpyDeviceToDevice));
+        HIP_TRY(hipMemcpy(len, s->d_st_len, o * sizeof(int32_t), hipMemcpyDeviceToDevice));
+        HIP_TRY(hipMemcpy(pass, s->d_st_pass, o * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+        HIP_TRY(hipMemcpy(g1, s->d_st_g1, o * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+        (void)hipFree(s->d_st_steps);
+        (void)hipFree(s->d_st_len);
+        (void)hipFree(s->d_st_pass);
+        (void)hipFree(s->d_st_g1);
+    }
+    s->d_st_steps = steps;
+    s->d_st_len = len;
+    s->d_st_pass = pass;
+    s->d_st_g1 = g1;
+    s->st_cap = cap;
+    return GFAL_OK;
+}
+
+// A children batch on one shard: [parent | step | slot] in, the paths written out on
+// the device, then the usual pipeline with k_child in place of the scans.  Counters
+// are left in s->d_counts like score_stage does.
+static int children_stage(gfal_scorer *s, const int32_t *parent, const int32_t *step, const int32_t *slot,
+                          int32_t n, int32_t max_len)
+{
+    int rc;
+    if ((rc = build_child_index(s))) return rc;
+    if (s->st_cap < 1) {
+        set_err("children batch without a path store (gfal_group_store_reserve)");
+        return GFAL_E_ARG;
+    }
+    const size_t n_in = (size_t)3 * n, n_out = (size_t)3 * n + 4;
+    const size_t n_paths_buf = (size_t)n + 1 + (size_t)n * (size_t)max_len;
+    if (s->have_last && (n_in > s->child_in_cap || (size_t)4 * n > s->child_tmp_cap ||
+                         n_paths_buf > s->path_off_cap || n_out > s->counts_cap))
+        HIP_TRY(hipStreamSynchronize(s->last_stream));
+    if ((rc = dev_reserve(&s->d_child_in, &s->child_in_cap, n_in))) return rc;
+    if ((rc = dev_reserve(&s->d_child_tmp, &s->child_tmp_cap, (size_t)4 * n))) return rc;
+    if ((rc = dev_reserve(&s->d_path_off, &s->path_off_cap, n_paths_buf))) return rc;
+    if ((rc = dev_reserve(&s->d_counts, &s->counts_cap, n_out))) return rc;
+    if ((rc = pinned_reserve(&s->h_in, &s->h_in_cap, n_in))) return rc;
+    if ((rc = pinned_reserve(&s->h_out, &s->h_out_cap, n_out))) return rc;
+    if (parent != s->h_in) {
+        memcpy(s->h_in, parent, (size_t)n * sizeof(int32_t));
+        memcpy(s->h_in + n, step, (size_t)n * sizeof(int32_t));
+        memcpy(s->h_in + 2 * (size_t)n, slot, (size_t)n * sizeof(int32_t));
+    }
+    hipStream_t st = s->stream;
+    if (s->have_last && s->last_stream != st) {
+        HIP_TRY(hipEventRecord(s->order_ev, s->last_stream));
+        HIP_TRY(hipStreamWaitEvent(st, s->order_ev, 0));
+    }
+    HIP_TRY(hipMemcpyAsync(s->d_child_in, s->h_in, n_in * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    ExtraCtx cx;
+    cx.mode = 2;
+    ChildBatch &b = cx.batch;
+    b.parent = s->d_child_in;
+    b.step = s->d_child_in + n;
+    b.slot = s->d_child_in + 2 * (size_t)n;
+    b.n = n;
+    b.st_steps = s->d_st_steps;
+    b.st_len = s->d_st_len;
+    b.st_pass = s->d_st_pass;
+    b.st_g1 = s->d_st_g1;
+    b.st_cap = s->st_cap;
+    b.root = s->d_child_tmp;
+    b.depth = s->d_child_tmp + n;
+    b.dpass = reinterpret_cast<uint32_t *>(s->d_child_tmp + 2 * (size_t)n);
+    b.dg1 = reinterpret_cast<uint32_t *>(s->d_child_tmp + 3 * (size_t)n);
+    hipLaunchKernelGGL(k_child_len, dim3(1), dim3(1024), 0, st, b, (int)max_len, (int)s->max_aln_len,
+                       s->d_path_off);
+    hipLaunchKernelGGL(k_child_copy, dim3((unsigned)n), dim3(256), 0, st, b, s->d_path_off,
+                       s->d_path_off + n + 1);
+    HIP_TRY(hipGetLastError());
+    ++s->n_children_calls;
+    rc = score_device_impl(s, s->d_path_off, s->d_path_off + n + 1, n, (int64_t)n * max_len, max_len, 1,
+                           s->d_counts, st, s->d_counts + (size_t)3 * n, &cx);
+    s->last_stream = st;
     s->have_last = true;
     return rc;
 }
@@ -4395,10 +5237,8 @@ struct gfal_group {
     bool pending = false;
     int32_t pend_paths = 0, pend_max_len = 0;
     int pend_filter = 0;
+    int pend_kind = 0;        // 0 plain, 1 paths kept in the store, 2 children batch
 };
-
-static int score_stage(gfal_scorer *s, const int32_t *path_off, const int32_t *path_steps, int32_t P,
-                       int32_t max_len, int filter);
 
 int gfal_group_create(gfal_scorer *const *scorers, int n, gfal_group **out)
 {
@@ -4443,14 +5283,20 @@ int gfal_group_uses_rccl(const gfal_group *g) { return g && !g->comms.empty() ? 
 
 // every device: paths in, the kernels, the all-reduce, counters and status words
 // on their way out -- nothing waited for
-static int group_enqueue(gfal_group *g, const int32_t *path_off, const int32_t *path_steps)
+// (kind 1: `slots` behind the paths; kind 2: path_off / path_steps / slots are the
+// batch's parent / step / slot arrays)
+static int group_enqueue(gfal_group *g, const int32_t *path_off, const int32_t *path_steps,
+                         const int32_t *slots = nullptr)
 {
     const size_t D = g->shards.size();
     const int32_t P = g->pend_paths;
     for (size_t d = 0; d < D; ++d) {
         gfal_scorer *s = g->shards[d];
         HIP_TRY(hipSetDevice(s->device));
-        const int rc = score_stage(s, path_off, path_steps, P, g->pend_max_len, g->pend_filter);
+        const int rc = g->pend_kind == 2
+                           ? children_stage(s, path_off, path_steps, slots, P, g->pend_max_len)
+                           : score_stage(s, path_off, path_steps, P, g->pend_max_len, g->pend_filter,
+                                         g->pend_kind == 1 ? slots : nullptr);
         if (rc) return rc;
     }
     const size_t n_cnt = (size_t)3 * P;
@@ -4486,7 +5332,7 @@ static int group_enqueue(gfal_group *g, const int32_t *path_off, const int32_t *
 }
 
 static int group_begin_impl(gfal_group *g, const int32_t *path_off, const int32_t *path_steps,
-                            int32_t n_paths, int filter)
+                            int32_t n_paths, int filter, const int32_t *slots = nullptr)
 {
     if (g->pending) {
         set_err("gfal_group_score_begin: the previous batch has not been collected");
@@ -4511,8 +5357,44 @@ static int group_begin_impl(gfal_group *g, const int32_t *path_off, const int32_
     g->pend_paths = n_paths;
     g->pend_max_len = max_len;
     g->pend_filter = filter;
+    g->pend_kind = slots ? 1 : 0;
+    if (slots)
+        for (gfal_scorer *s : g->shards)
+            if (s->st_cap < 1) {
+                set_err("gfal_group_score_store_begin without a path store (gfal_group_store_reserve)");
+                return GFAL_E_ARG;
+            }
     for (gfal_scorer *s : g->shards) ++s->n_score_calls;
-    const int rc = group_enqueue(g, path_off, path_steps);
+    const int rc = group_enqueue(g, path_off, path_steps, slots);
+    g->pending = rc == GFAL_OK;
+    return rc;
+}
+
+static int group_children_impl(gfal_group *g, int32_t n, const int32_t *parent, const int32_t *step,
+                               const int32_t *slot, int32_t max_len)
+{
+    if (g->pending) {
+        set_err("gfal_group_score_children_begin: the previous batch has not been collected");
+        return GFAL_E_ARG;
+    }
+    if (max_len < 2 || max_len > GFAL_MAX_STEPS) return GFAL_E_RANGE;
+    for (int32_t i = 0; i < n; ++i) {
+        const int32_t st = step[i];
+        if (st < 0 || ((st & ~GFAL_STEP_OTHER) >> 1) >= g->shards[0]->n_nodes) {
+            set_err("child %d: node id out of range", i);
+            return GFAL_E_RANGE;
+        }
+        if (parent[i] < 0 && ~parent[i] >= i) {
+            set_err("child %d: an in-batch parent must come earlier in the batch", i);
+            return GFAL_E_ARG;
+        }
+    }
+    g->pend_paths = n;
+    g->pend_max_len = max_len;
+    g->pend_filter = 1;
+    g->pend_kind = 2;
+    for (gfal_scorer *s : g->shards) ++s->n_score_calls;
+    const int rc = group_enqueue(g, parent, step, slot);
     g->pending = rc == GFAL_OK;
     return rc;
 }
@@ -4563,9 +5445,12 @@ static int group_end_impl(gfal_group *g, uint32_t *bad, uint32_t *good, uint32_t
             }
             return GFAL_OK;
         }
-        // the batch is still in shard 0's pinned staging buffer: [offsets | steps]
+        // the batch is still in shard 0's pinned staging buffer: [offsets | steps | slots],
+        // or [parent | step | slot] of a children batch (re-running one is idempotent:
+        // the store receives the same paths and counters again)
         const int32_t *h_in = g->shards[0]->h_in;
-        const int rc = group_enqueue(g, h_in, h_in + P + 1);
+        const int rc = g->pend_kind == 2 ? group_enqueue(g, h_in, h_in + P, h_in + 2 * (size_t)P)
+                                         : group_enqueue(g, h_in, h_in + P + 1, h_in + P + 1 + h_in[P]);
         if (rc) return rc;
     }
     set_err("exact-DP worklist kept overflowing");
@@ -4578,6 +5463,38 @@ int gfal_group_score_begin(gfal_group *g, const int32_t *path_off, const int32_t
     if (!g || n_paths < 1) return GFAL_E_ARG;
     if (!path_off || !path_steps || path_off[0] != 0) return GFAL_E_ARG;
     return no_throw([&] { return group_begin_impl(g, path_off, path_steps, n_paths, filter); });
+}
+
+int gfal_group_store_reserve(gfal_group *g, int64_t n_slots)
+{
+    if (!g || n_slots < 1 || n_slots > ((int64_t)1 << 30)) return GFAL_E_ARG;
+    return no_throw([&] {
+        if (g->pending) {
+            set_err("gfal_group_store_reserve while a batch is in flight");
+            return GFAL_E_ARG;
+        }
+        for (gfal_scorer *s : g->shards) {
+            int rc = build_child_index(s);
+            if (rc == GFAL_OK) rc = store_reserve(s, n_slots);
+            if (rc) return rc;
+        }
+        return GFAL_OK;
+    });
+}
+
+int gfal_group_score_store_begin(gfal_group *g, const int32_t *path_off, const int32_t *path_steps,
+                                 int32_t n_paths, const int32_t *slots)
+{
+    if (!g || n_paths < 1 || !slots) return GFAL_E_ARG;
+    if (!path_off || !path_steps || path_off[0] != 0) return GFAL_E_ARG;
+    return no_throw([&] { return group_begin_impl(g, path_off, path_steps, n_paths, 1, slots); });
+}
+
+int gfal_group_score_children_begin(gfal_group *g, int32_t n, const int32_t *parent, const int32_t *step,
+                                    const int32_t *slot, int32_t max_path_len)
+{
+    if (!g || n < 1 || !parent || !step || !slot) return GFAL_E_ARG;
+    return no_throw([&] { return group_children_impl(g, n, parent, step, slot, max_path_len); });
 }
 
 int gfal_group_score_end(gfal_group *g, uint32_t *bad, uint32_t *good, uint32_t *unaligned)

@@ -255,6 +255,54 @@ public:
     {
         return begin(off, steps, filter) && end(bad, good);
     }
+    // Search mode (gfal_group_score_children): scored paths stay on the devices and a
+    // candidate is scored from its parent.  The longest alignment of any shard bounds
+    // the parents that may be used that way.
+    int32_t max_aln_len() const
+    {
+        int32_t m = 0;
+        for (gfal_scorer *h : shards_) {
+            gfal_info info;
+            if (gfal_scorer_get_info(h, &info) == GFAL_OK) m = std::max(m, info.max_aln_len);
+        }
+        return m;
+    }
+    bool store_reserve(int64_t n_slots)
+    {
+        if (n_aln_ == 0) return true;
+        const int rc = gfal_group_store_reserve(group_, n_slots);
+        if (rc != GFAL_OK) {
+            fprintf(stderr, "Error: scorer: %s (%s)\n", gfal_strerror(rc), gfal_last_error());
+            return false;
+        }
+        return true;
+    }
+    bool begin_store(const std::vector<int32_t> &off, const std::vector<int32_t> &steps,
+                     const std::vector<int32_t> &slots)
+    {
+        pending_paths_ = off.size() - 1;
+        if (n_aln_ == 0 || pending_paths_ == 0) return true;
+        const int rc = gfal_group_score_store_begin(group_, off.data(), steps.data(), (int32_t)pending_paths_,
+                                                    slots.data());
+        if (rc != GFAL_OK) {
+            fprintf(stderr, "Error: scorer: %s (%s)\n", gfal_strerror(rc), gfal_last_error());
+            return false;
+        }
+        return true;
+    }
+    bool begin_children(const std::vector<int32_t> &parent, const std::vector<int32_t> &step,
+                        const std::vector<int32_t> &slot, int32_t max_len)
+    {
+        pending_paths_ = parent.size();
+        if (n_aln_ == 0 || pending_paths_ == 0) return true;
+        const int rc = gfal_group_score_children_begin(group_, (int32_t)pending_paths_, parent.data(),
+                                                       step.data(), slot.data(), max_len);
+        if (rc != GFAL_OK) {
+            fprintf(stderr, "Error: scorer: %s (%s)\n", gfal_strerror(rc), gfal_last_error());
+            return false;
+        }
+        return true;
+    }
     uint64_t dp_pairs() const { return dp_pairs_; }   // pairs that needed the exact DP so far
     // fw / rc traceback scores of one path against every alignment, in input order
     bool pair_scores(const std::vector<int32_t> &path, std::vector<int32_t> &fw,
@@ -294,6 +342,9 @@ struct SearchOptions {
     // time, but the search stalls every few pops, so there is little host work to hide and
     // the extra batches cost more than they save (0.24 s against 0.19 s): off by default.
     bool prefetch = false;
+    // Candidates scored from their parents on the device (same counters, less work;
+    // gfal_group_score_children).  GFALIGN_INCREMENTAL=0 scores every candidate in full.
+    bool incremental = true;
 };
 
 // reference src/eval.cpp:110-193
@@ -344,6 +395,13 @@ public:
         for (size_t u = 0; u < record_of_.size(); ++u)
             if (record_of_[u] >= 0) allowance_[u] = table.records[(size_t)record_of_[u]].count;
 
+        incr_ = opt_.incremental && !opt_.prefetch && scorer_.n_aln() > 0;
+        if (incr_) {
+            min_parent_ = (size_t)std::max<int32_t>(1, scorer_.max_aln_len());
+            store_cap_ = 1 << 14;
+            if (!scorer_.store_reserve(store_cap_)) return EXIT_FAILURE;
+        }
+
         auto first = std::make_unique<Node>();
         first->path.push_back(GFAL_STEP_OTHER | (int32_t)(src_uid << 1));   // :130, orientation '0'
         first->uniques = 1;
@@ -389,6 +447,7 @@ public:
     }
 
     uint64_t scored_paths() const { return scored_; }
+    uint64_t scored_in_full() const { return incr_ ? full_scored_ : scored_; }
     uint64_t batches() const { return batches_; }
     uint64_t prefetch_hits() const { return prefetch_hits_; }
     uint64_t prefetch_misses() const { return prefetch_misses_; }
@@ -408,6 +467,11 @@ private:
         bool scored = false;            // bad / good are known (queue entries, finished batches)
         bool kids_made = false, kids_scored = false;
         std::vector<std::unique_ptr<Node>> kids;   // extensions, adjacency order
+        // search mode: where the path is kept on the devices (-1: nowhere), and where
+        // the entry sits in the batch being collected (>= 0: the children sub-batch,
+        // < 0: ~index in the sub-batch scored in full)
+        int32_t slot = -1, batch_at = 0;
+        int32_t batch_depth = 0;   // ancestors inside the children sub-batch being collected
     };
     struct Key {
         int32_t alt;
@@ -464,6 +528,11 @@ private:
         batch_parents_.clear();
         batch_off_.assign(1, 0);
         batch_steps_.clear();
+        batch_slots_.clear();
+        ch_parent_.clear();
+        ch_step_.clear();
+        ch_slot_.clear();
+        ch_max_len_ = 2;
         size_t n_paths = 0;
         level_.clear();
         auto it = queue_.begin();
@@ -481,31 +550,79 @@ private:
                 if (!e->kids_made) {
                     make_kids(*e);
                     batch_parents_.push_back(e);
+                    // search mode: a kid is scored from its parent when the parent is long
+                    // enough (no alignment longer than it) and is on the devices -- kept
+                    // there by an earlier batch, or itself a child of this one
+                    const bool from_parent = incr_ && e->path.size() >= min_parent_ &&
+                                             !(e->path.back() & GFAL_STEP_OTHER) &&
+                                             (e->slot >= 0 || e->batch_at > 0);
                     for (auto &c : e->kids) {
-                        batch_steps_.insert(batch_steps_.end(), c->path.begin(), c->path.end());
-                        batch_off_.push_back((int32_t)batch_steps_.size());
+                        if (incr_ && !c->at_destination && c->path.size() < GFAL_MAX_STEPS &&
+                            c->path.size() >= min_parent_)
+                            c->slot = take_slot();
+                        if (from_parent) {
+                            // (batch_at > 0: the parent is entry batch_at - 1 of this very sub-batch)
+                            ch_parent_.push_back(e->batch_at > 0 ? ~(e->batch_at - 1) : e->slot);
+                            ch_step_.push_back(c->path.back());
+                            ch_slot_.push_back(c->slot);
+                            ch_max_len_ = std::max(ch_max_len_, (int32_t)c->path.size());
+                            c->batch_at = (int32_t)ch_parent_.size();
+                            c->batch_depth = e->batch_at > 0 ? e->batch_depth + 1 : 0;
+                        } else {
+                            batch_steps_.insert(batch_steps_.end(), c->path.begin(), c->path.end());
+                            batch_off_.push_back((int32_t)batch_steps_.size());
+                            batch_slots_.push_back(c->slot);
+                            c->batch_at = -(int32_t)batch_slots_.size();
+                        }
                         ++n_paths;
                     }
                 }
+                // (a chain of in-batch parents is walked by one device thread per child:
+                // beyond 48 levels the rest of the dive waits for the next batch)
                 for (auto &c : e->kids)
-                    if (!c->at_destination && c->path.size() < GFAL_MAX_STEPS) next_.push_back(c.get());
+                    if (!c->at_destination && c->path.size() < GFAL_MAX_STEPS && c->batch_depth < 48)
+                        next_.push_back(c.get());
             }
             level_.swap(next_);
         }
-        if (dump_ && n_paths) {   // GFALIGN_DUMP_BATCHES: the candidate batches, for benchmarks
-            const int32_t head[2] = {(int32_t)n_paths, (int32_t)batch_steps_.size()};
+        if (dump_ && n_paths) {   // GFALIGN_DUMP_BATCHES: the candidate batches (full paths), for benchmarks
+            std::vector<int32_t> off{0}, steps;
+            for (Node *e : batch_parents_)
+                for (auto &c : e->kids) {
+                    steps.insert(steps.end(), c->path.begin(), c->path.end());
+                    off.push_back((int32_t)steps.size());
+                }
+            const int32_t head[2] = {(int32_t)n_paths, (int32_t)steps.size()};
             fwrite(head, sizeof(int32_t), 2, dump_);
-            fwrite(batch_off_.data(), sizeof(int32_t), batch_off_.size(), dump_);
-            fwrite(batch_steps_.data(), sizeof(int32_t), batch_steps_.size(), dump_);
+            fwrite(off.data(), sizeof(int32_t), off.size(), dump_);
+            fwrite(steps.data(), sizeof(int32_t), steps.size(), dump_);
         }
         t_collect_ += now_s() - t0;
     }
 
     bool submit()
     {
-        if (batch_off_.size() <= 1) return true;            // nothing to score
+        if (batch_off_.size() <= 1 && ch_parent_.empty()) return true;            // nothing to score
         const double t0 = now_s();
-        if (!scorer_.begin(batch_off_, batch_steps_, true)) return false;     // :162
+        if (incr_) {
+            // the sub-batch scored in full first (its paths are kept: children of this
+            // very collect may name them), then the children; both waited for here
+            bad_.clear();
+            good_.clear();
+            ch_bad_.clear();
+            ch_good_.clear();
+            if (batch_off_.size() > 1 &&
+                !(scorer_.begin_store(batch_off_, batch_steps_, batch_slots_) && scorer_.end(bad_, good_)))
+                return false;
+            full_scored_ += batch_off_.size() - 1;
+            if (!ch_parent_.empty() &&
+                !(scorer_.begin_children(ch_parent_, ch_step_, ch_slot_, ch_max_len_) &&
+                  scorer_.end(ch_bad_, ch_good_)))
+                return false;
+            results_ready_ = true;
+        } else if (!scorer_.begin(batch_off_, batch_steps_, true)) {     // :162
+            return false;
+        }
         flight_parents_.swap(batch_parents_);
         in_flight_ = true;
         t_score_ += now_s() - t0;
@@ -515,16 +632,30 @@ private:
     bool finish()
     {
         const double t0 = now_s();
-        if (!scorer_.end(bad_, good_)) return false;
+        if (!results_ready_ && !scorer_.end(bad_, good_)) return false;
+        results_ready_ = false;
         size_t k = 0;
         for (Node *e : flight_parents_) {
             for (auto &c : e->kids) {
-                c->bad = bad_[k];
-                c->good = good_[k];
+                if (incr_) {
+                    const bool ch = c->batch_at > 0;
+                    const size_t at = ch ? (size_t)(c->batch_at - 1) : (size_t)(-c->batch_at - 1);
+                    c->bad = ch ? ch_bad_[at] : bad_[at];
+                    c->good = ch ? ch_good_[at] : good_[at];
+                    c->batch_at = 0;
+                    c->batch_depth = 0;
+                } else {
+                    c->bad = bad_[k];
+                    c->good = good_[k];
+                }
                 c->scored = true;
                 ++k;
             }
             e->kids_scored = true;
+            if (e->slot >= 0) {          // its extensions exist: nothing names this path again
+                free_slots_.push_back(e->slot);
+                e->slot = -1;
+            }
         }
         flight_parents_.clear();
         in_flight_ = false;
@@ -572,6 +703,32 @@ private:
     uint64_t prefetch_hits_ = 0, prefetch_misses_ = 0;
     std::vector<int32_t> batch_off_, batch_steps_;
     std::vector<uint32_t> bad_, good_;
+    // search mode: the children sub-batch of the collect, the slots of the other one,
+    // and the slots of the device-side path store
+    bool incr_ = false, results_ready_ = false;
+    size_t min_parent_ = 1;
+    std::vector<int32_t> batch_slots_, ch_parent_, ch_step_, ch_slot_, free_slots_;
+    std::vector<uint32_t> ch_bad_, ch_good_;
+    int32_t ch_max_len_ = 2, next_slot_ = 0;
+    int64_t store_cap_ = 0;
+    uint64_t full_scored_ = 0;
+    bool store_failed_ = false;
+    int32_t take_slot()
+    {
+        if (!free_slots_.empty()) {
+            const int32_t s = free_slots_.back();
+            free_slots_.pop_back();
+            return s;
+        }
+        if (next_slot_ >= store_cap_) {        // (no batch is in flight while one is collected)
+            if (store_failed_ || !scorer_.store_reserve(store_cap_ * 2)) {
+                store_failed_ = true;          // out of device memory: this path is not kept,
+                return -1;                     // its extensions are scored in full
+            }
+            store_cap_ *= 2;
+        }
+        return next_slot_++;
+    }
     bool in_flight_ = false;
     FILE *dump_ = nullptr;
 };

@@ -67,6 +67,10 @@ EXPORTS = {
                                         _u32p, _u32p, _u32p]),
     "gfal_group_score_begin": (ctypes.c_int, [ctypes.c_void_p, _i32p, _i32p, ctypes.c_int32, ctypes.c_int]),
     "gfal_group_score_end": (ctypes.c_int, [ctypes.c_void_p, _u32p, _u32p, _u32p]),
+    "gfal_group_store_reserve": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64]),
+    "gfal_group_score_store_begin": (ctypes.c_int, [ctypes.c_void_p, _i32p, _i32p, ctypes.c_int32, _i32p]),
+    "gfal_group_score_children_begin": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, _i32p, _i32p, _i32p,
+                                                       ctypes.c_int32]),
     "gfal_scorer_sync_status": (ctypes.c_int, [ctypes.c_void_p]),
     "gfal_scorer_pair_scores": (ctypes.c_int, [ctypes.c_void_p, _i32p, ctypes.c_int32,
                                                _i32p, _i32p]),
@@ -286,6 +290,31 @@ class Group:
         _check(self._lib.gfal_group_score_end(self._h, _ptr(bad, ctypes.c_uint32), _ptr(good, ctypes.c_uint32),
                                               _ptr(una, ctypes.c_uint32)))
         return bad, good, una
+
+    # ---- search mode: paths kept on the devices, children scored from their parents ----
+    def store_reserve(self, n_slots):
+        _check(self._lib.gfal_group_store_reserve(self._h, int(n_slots)))
+
+    def score_store(self, path_off, path_steps, slots):
+        """evaluate_paths(filter=True) that also keeps path p in slot slots[p] (-1: not kept)."""
+        path_off, path_steps, slots = _i32(path_off), _i32(path_steps), _i32(slots)
+        self._pending_paths = len(path_off) - 1
+        assert len(slots) == self._pending_paths
+        _check(self._lib.gfal_group_score_store_begin(
+            self._h, _ptr(path_off, ctypes.c_int32), _ptr(path_steps, ctypes.c_int32), self._pending_paths,
+            _ptr(slots, ctypes.c_int32)))
+        return self.end()
+
+    def score_children(self, parent, step, slot, max_path_len):
+        """child i = parent[i] + step[i] (parent >= 0: store slot; < 0: ~index of an
+        earlier child of this batch), kept in slot[i] (-1: not kept)."""
+        parent, step, slot = _i32(parent), _i32(step), _i32(slot)
+        self._pending_paths = len(parent)
+        assert len(step) == len(slot) == len(parent)
+        _check(self._lib.gfal_group_score_children_begin(
+            self._h, len(parent), _ptr(parent, ctypes.c_int32), _ptr(step, ctypes.c_int32),
+            _ptr(slot, ctypes.c_int32), int(max_path_len)))
+        return self.end()
 
     def close(self):
         if self._h:

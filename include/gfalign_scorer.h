@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define GFAL_ABI_VERSION 2
+#define GFAL_ABI_VERSION 3
 
 /* include/alignments.h:246 (MAX_N 1001): longest path / alignment accepted. */
 #define GFAL_MAX_STEPS 1000
@@ -199,6 +199,41 @@ int  gfal_group_score_begin(gfal_group *g,
                             const int32_t *path_off, const int32_t *path_steps,
                             int32_t n_paths, int filter);
 int  gfal_group_score_end(gfal_group *g, uint32_t *bad, uint32_t *good, uint32_t *unaligned);
+
+/*
+ * Search mode: a candidate scored from its parent.  `gfalign search` only ever
+ * scores `parent + one step` (src/eval.cpp:146-162), and with the filter on the
+ * counters of src/eval.cpp:92-98 follow from the parent's: the alignments that
+ * newly pass the filter all carry the new node, the ones that newly become a
+ * subpath all end at the new step, and the start-overhang pairs of the exact DP
+ * all carry the path's first node (scorer.hip "Search mode", tests/incr_model.py).
+ * The result is bit-identical to gfal_group_score on the full paths; only the work
+ * shrinks from all alignments to two inverted lists.  An algorithmic shortcut in
+ * the sense of SURVEY.md 8(d): bench.py reports it next to the headline figure.
+ *
+ *   gfal_group_store_reserve         room for n_slots scored paths on every shard
+ *                                    (4 KB each; grows, keeps what is there); the
+ *                                    first call also builds the index on the devices
+ *   gfal_group_score_store_begin     gfal_group_score_begin with filter = 1 that also
+ *                                    keeps path p in slot slots[p] (-1: not kept)
+ *   gfal_group_score_children_begin  child i = parent[i] + step[i]; parent[i] >= 0 is
+ *                                    a store slot, parent[i] < 0 the child ~parent[i]
+ *                                    of this batch (it must come earlier); the child
+ *                                    is kept in slot[i] (-1: not kept).  Every parent
+ *                                    must be at least as long as the longest
+ *                                    alignment (gfal_info.max_aln_len) -- shorter
+ *                                    paths go through score_store -- and no child
+ *                                    longer than max_path_len.
+ * Both are collected with gfal_group_score_end.  Slots are the caller's to manage:
+ * a slot may be reused once no later batch names it as a parent.
+ */
+int  gfal_group_store_reserve(gfal_group *g, int64_t n_slots);
+int  gfal_group_score_store_begin(gfal_group *g,
+                                  const int32_t *path_off, const int32_t *path_steps,
+                                  int32_t n_paths, const int32_t *slots);
+int  gfal_group_score_children_begin(gfal_group *g, int32_t n,
+                                     const int32_t *parent, const int32_t *step,
+                                     const int32_t *slot, int32_t max_path_len);
 
 /* Status word of the most recent score_device call (blocks on its stream). */
 int gfal_scorer_sync_status(gfal_scorer *s);

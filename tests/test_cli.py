@@ -244,6 +244,16 @@ def test_search_on_a_synthetic_tangle_matches_oracle(cli, gpu, tmp_path):
         assert rc == 0, err
         outs.append(out)
     assert outs[0] == outs[1] == outs[2]          # batching never changes the output
+    # candidates scored from their parents on the device (the default) or all in full
+    for spec in ("1", "128"):
+        rc, out, err = run(cli, base, env={"GFALIGN_SPECULATE": spec, "GFALIGN_INCREMENTAL": "0"})
+        assert rc == 0, err
+        assert out == outs[0]
+    rc, out, err = run(cli, base + ["--verbose"], env={"GFALIGN_SPECULATE": "128"})
+    assert rc == 0 and out == outs[0], err
+    import re
+    m = re.search(r"scored (\d+) candidate paths in \d+ batches, (\d+) of them in full", err)
+    assert m and int(m.group(2)) < int(m.group(1)), err       # the search did use the shortcut
     # nor does keeping a further batch in flight while the host pops
     for spec in ("7", "128"):
         rc, out, err = run(cli, base, env={"GFALIGN_SPECULATE": spec, "GFALIGN_PREFETCH": "1"})
