@@ -2905,6 +2905,7 @@ __global__ void k_fill_i32(int32_t *p, long long n, int32_t v)
 // G1); a batch names every child as (parent, step), the parent being a slot or
 // an earlier child of the same batch.
 // --------------------------------------------------------------------------
+namespace {
 constexpr int STORE_STRIDE = GFAL_MAX_STEPS;     // int32 steps per store slot
 constexpr int CHILD_MAX_DEPTH = 64;              // in-batch ancestors of one child
 constexpr int CHILD_THREADS = 256;
@@ -2913,7 +2914,9 @@ constexpr uint32_t ST_BAD_CHILD = 8u;            // status flag: bad parent refe
 
 struct ChildIndex {              // built once per scorer, on the device
     const uint32_t *inv_off;     // [n_local * N_CLASSES + 1] (node, DP length class) -> range of inv_slot
-    const uint32_t *inv_slot;    // lanes (item * 64 + lane) whose alignment has the node
+    // per list entry: {lane (item * 64 + lane), m | first step << 16, steps 1..2, steps 3..4} of an
+    // alignment that has the node: alignments of up to five steps need no further load
+    const uint4 *inv_ent;
     const uint32_t *ct_key;      // content table: representative lane or CT_EMPTY
     const uint32_t *ct_hash;     // its whash
     const uint32_t *ct_mult;     // alignments with exactly that content (weights summed)
@@ -2935,7 +2938,7 @@ __device__ __forceinline__ bool lane_same_content(const Items &items, uint32_t x
 // one thread per lane: distinct nodes of its alignment -> cnt[node]++ (fill == NULL)
 // or inv_slot[cursor[node]++] = lane
 __global__ void k_inv_build(Items items, const int32_t *__restrict__ slot_orig, uint32_t n_slots,
-                            uint32_t *__restrict__ cnt_or_cursor, uint32_t *__restrict__ fill)
+                            uint32_t *__restrict__ cnt_or_cursor, uint4 *__restrict__ fill)
 {
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= n_slots || slot_orig[slot] < 0) return;
@@ -2948,7 +2951,10 @@ __global__ void k_inv_build(Items items, const int32_t *__restrict__ slot_orig, 
         for (int u = 0; u < t && !seen; ++u) seen = ((uint32_t)bp[(size_t)u * WAVE] >> 1) == node;
         if (seen) continue;
         const uint32_t at = atomicAdd(&cnt_or_cursor[node * N_CLASSES + (uint32_t)length_class(m)], 1u);
-        if (fill) fill[at] = slot;
+        if (fill) {
+            auto st = [&](int k) -> uint32_t { return k < m ? (uint32_t)bp[(size_t)k * WAVE] : 0u; };
+            fill[at] = make_uint4(slot, (uint32_t)m | (st(0) << 16), st(1) | (st(2) << 16), st(3) | (st(4) << 16));
+        }
     }
 }
 
@@ -3018,9 +3024,14 @@ struct ChildBatch {
 
 // lengths and offsets of the batch's paths (one workgroup)
 __global__ __launch_bounds__(1024) void k_child_len(ChildBatch b, int max_len, int min_parent_len,
-                                                    int32_t *__restrict__ path_off)
+                                                    int32_t *__restrict__ path_off,
+                                                    uint32_t *__restrict__ status)
 {
     __shared__ uint32_t part[1024];
+    // a children batch is not sorted by length (k_child's cost does not follow it): this
+    // kernel also does what k_len_sort_block does besides sorting, clearing the status words
+    if (threadIdx.x < 8) status[threadIdx.x] = 0;
+    __syncthreads();
     const int tid = threadIdx.x, per = (b.n + 1023) / 1024;
     const int lo = min(tid * per, b.n), hi = min(lo + per, b.n);
     uint32_t sum = 0;
@@ -3048,7 +3059,8 @@ __global__ __launch_bounds__(1024) void k_child_len(ChildBatch b, int max_len, i
             if (l0 < 1 || l0 < min_parent_len || L > max_len || L > GFAL_MAX_STEPS) good = false;
         }
         if (b.slot[i] >= b.st_cap) good = false;
-        if (!good) {       // root = -1 marks it; k_child_resolve raises ST_BAD_CHILD
+        if (!good) {       // root = -1 marks it for the kernels behind
+            atomicOr(status, ST_BAD_CHILD);
             L = 1;
             d = 1;
         }
@@ -3138,9 +3150,10 @@ __device__ __forceinline__ uint32_t ct_lookup(const ChildArgs &a, uint32_t h, in
             const uint32_t it = key >> 6;
             if ((int)a.items.len[it] == M) {
                 const uint16_t *bp = a.items.steps + (size_t)a.items.base[it] * WAVE + (key & 63u);
-                bool eq = true;
-                for (int t = 0; t < M && eq; ++t)
-                    eq = (uint32_t)bp[(size_t)t * WAVE] == ((uint32_t)step[start + dir * t] ^ flip);
+                bool eq = true;          // (no early exit: the loads go out together)
+#pragma unroll 8
+                for (int t = 0; t < M; ++t)
+                    eq &= (uint32_t)bp[(size_t)t * WAVE] == ((uint32_t)step[start + dir * t] ^ flip);
                 if (eq) return a.ix.ct_mult[idx];
             }
         }
@@ -3154,7 +3167,7 @@ __device__ __forceinline__ uint32_t ct_lookup(const ChildArgs &a, uint32_t h, in
 // the lane's own LDS column, so the divergent per-lane loops below read LDS, not HBM.
 constexpr int CHILD_WAVES = CHILD_THREADS / WAVE;
 constexpr int CHILD_STAGE_PAIRS = 16;
-constexpr int CHILD_WL_BUF = 4096;             // worklist entries a workgroup gathers before it appends them
+constexpr int CHILD_WL_BUF = 1024;             // worklist entries a workgroup gathers before it appends them
 constexpr int CHILD_STATIC_LDS = CHILD_WAVES * CHILD_STAGE_PAIRS * WAVE * 4 + CHILD_WL_BUF * 8 + 256;
 
 template <bool W>
@@ -3187,7 +3200,7 @@ __global__ __launch_bounds__(CHILD_THREADS) void k_child(ChildArgs a)
     const uint32_t *lid32 = reinterpret_cast<const uint32_t *>(lid);
     const int n = img[a.L.len_at()];
     if (n < 2) return;                       // (rejected child: nothing to add)
-    const int child = a.order[q];
+    const int child = a.order ? a.order[q] : q;
     const uint32_t s = lds_u16(step32, (uint32_t)(n - 1)), s_lid = lds_u16(lid32, (uint32_t)(n - 1));
     const uint32_t a0 = lds_u16(step32, 0u), a0_lid = lds_u16(lid32, 0u);
     const int cap = min(a.max_aln_len, n);   // longest window that can be an alignment
@@ -3244,15 +3257,20 @@ __global__ __launch_bounds__(CHILD_THREADS) void k_child(ChildArgs a)
     uint32_t b0 = 0;
     const uint16_t *bp = nullptr;
     bool staged = false;
-    auto load_B = [&](uint32_t slot) -> int {
-        const uint4 h = a.items.hdr[slot >> 6];          // base, pbase, common, len
-        const int m = (int)h.w;
-        bp = a.items.steps + (size_t)h.x * WAVE + (slot & 63u);
-        b0 = bp[0];
+    auto load_B = [&](const uint4 ent) -> int {
+        const uint32_t slot = ent.x;
+        const int m = (int)(ent.y & 0xFFFFu);
+        b0 = ent.y >> 16;
         staged = m <= 2 * CHILD_STAGE_PAIRS + 1;
-        if (staged) {
-            const uint32_t *pp = a.items.pairs + (size_t)h.y * WAVE + (slot & 63u);
-            for (int j = 0; j < m / 2; ++j) mine[j][lane] = pp[(size_t)j * WAVE];
+        mine[0][lane] = ent.z;
+        mine[1][lane] = ent.w;
+        if (m > 5) {                                         // the rest of a longer alignment
+            const uint4 h = a.items.hdr[slot >> 6];          // base, pbase, common, len
+            bp = a.items.steps + (size_t)h.x * WAVE + (slot & 63u);
+            if (staged) {
+                const uint32_t *pp = a.items.pairs + (size_t)h.y * WAVE + (slot & 63u);
+                for (int j = 2; j < m / 2; ++j) mine[j][lane] = pp[(size_t)j * WAVE];
+            }
         }
         return m;
     };
@@ -3266,8 +3284,9 @@ __global__ __launch_bounds__(CHILD_THREADS) void k_child(ChildArgs a)
     if (is_new) {      // the alignments that carry the new node: which of them pass the filter now
         const uint32_t lo = a.ix.inv_off[s_lid * N_CLASSES], hi = a.ix.inv_off[(s_lid + 1u) * N_CLASSES];
         for (uint32_t e = lo + g; e < hi; e += stride) {
-            const uint32_t slot = a.ix.inv_slot[e];
-            const int m = load_B(slot);
+            const uint4 ent = a.ix.inv_ent[e];
+            const uint32_t slot = ent.x;
+            const int m = load_B(ent);
             bool pass = true;
             for (int t = 0; t < m && pass; ++t) pass = on_path(B(t));
             if (pass) newpass += W ? a.items.weight[slot] : 1u;
@@ -3314,8 +3333,9 @@ __global__ __launch_bounds__(CHILD_THREADS) void k_child(ChildArgs a)
                 uint32_t slot = 0;
                 int m = 0;
                 if (e < hi) {
-                    slot = a.ix.inv_slot[e];
-                    m = load_B(slot);
+                    const uint4 ent = a.ix.inv_ent[e];
+                    slot = ent.x;
+                    m = load_B(ent);
                     if (m >= 2 && m <= n) {
                         // a proper suffix of B (of rc(B)) equals a prefix of the path
                         for (int t = 1; t < m && !fw; ++t)
@@ -3394,34 +3414,38 @@ __global__ __launch_bounds__(CHILD_THREADS) void k_child(ChildArgs a)
     }
 }
 
-// Pass / G1 of every child from its stored ancestor's and the deltas on the way;
-// into the counters (by image slot) and into the child's store slot
-__global__ void k_child_resolve(ChildBatch b, const int32_t *__restrict__ order, int n_paths,
-                                uint32_t n_empty, uint32_t *__restrict__ counts,
-                                uint32_t *__restrict__ status)
+// Pass / G1 of every child from its stored ancestor's and the deltas on the way: into
+// the child's store slot and, with what the DP kernels added, into the caller's
+// counters (a children batch is not sorted: image slot = child index; this is its
+// k_unpermute).  counts[q] holds  -#candidates + the DP's bad,  counts[n + q]  the
+// zero-step alignments + the DP's good.
+__global__ void k_child_resolve(ChildBatch b, int n_paths, uint32_t n_empty,
+                                const uint32_t *__restrict__ counts, uint32_t *__restrict__ out,
+                                const uint32_t *__restrict__ status, uint32_t *__restrict__ status_copy)
 {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (status_copy && q < 4) status_copy[q] = status[q];
     if (q >= n_paths) return;
-    const int i = order[q];
-    const int r = b.root[i];
-    if (r < 0) {           // bad parent reference, slot or length (k_child_len)
-        atomicOr(status, ST_BAD_CHILD);
-        return;
+    const int r = b.root[q];
+    uint32_t pass = 0, g1 = n_empty;
+    if (r >= 0) {
+        pass = b.st_pass[r];
+        g1 = b.st_g1[r];
+        int j = q;
+        for (int k = b.depth[q]; k > 0; --k) {
+            pass += b.dpass[j];
+            g1 += b.dg1[j];
+            j = ~b.parent[j];
+        }
+        const int slot = b.slot[q];
+        if (slot >= 0) {
+            b.st_pass[slot] = pass;
+            b.st_g1[slot] = g1;
+        }
     }
-    uint32_t pass = b.st_pass[r], g1 = b.st_g1[r];
-    int j = i;
-    for (int k = b.depth[i]; k > 0; --k) {
-        pass += b.dpass[j];
-        g1 += b.dg1[j];
-        j = ~b.parent[j];
-    }
-    atomicAdd(&counts[q], pass - g1);
-    atomicAdd(&counts[n_paths + q], g1 - n_empty);
-    const int slot = b.slot[i];
-    if (slot >= 0) {
-        b.st_pass[slot] = pass;
-        b.st_g1[slot] = g1;
-    }
+    out[q] = counts[q] + (pass - g1);
+    out[n_paths + q] = counts[n_paths + q] + (g1 - n_empty);
+    out[2 * n_paths + q] = counts[2 * n_paths + q];
 }
 
 // full scoring with the store: good-without-DP per image slot, taken between the
@@ -3460,6 +3484,7 @@ __global__ __launch_bounds__(256) void k_store_paths(const int32_t *__restrict__
         st_g1[slot] = g1_tmp[q];
     }
 }
+}  // namespace
 
 // --------------------------------------------------------------------------
 // host side
@@ -3539,7 +3564,8 @@ struct gfal_scorer {
     // search mode (gfal_group_score_children): inverted lists by node and the content
     // table, built on the device at the first use; the path store; per-call scratch
     bool child_index = false;
-    uint32_t *d_inv_off = nullptr, *d_inv_slot = nullptr;
+    uint32_t *d_inv_off = nullptr;
+    uint4 *d_inv_ent = nullptr;
     uint32_t *d_ct_key = nullptr, *d_ct_hash = nullptr, *d_ct_mult = nullptr;
     uint32_t ct_mask = 0;
     int32_t *d_st_steps = nullptr, *d_st_len = nullptr;
@@ -3618,7 +3644,7 @@ void free_scorer(gfal_scorer *s)
                     s->d_item_len,   s->d_slot_orig, s->d_status,     s->d_worklist,
                     s->d_worklist_sorted, s->d_wl_bins,
                     s->d_rows,       s->d_images,    s->d_path_off,   s->d_path_steps,
-                    s->d_counts,     s->d_inv_off,   s->d_inv_slot,   s->d_ct_key,
+                    s->d_counts,     s->d_inv_off,   s->d_inv_ent,    s->d_ct_key,
                     s->d_ct_hash,    s->d_ct_mult,   s->d_st_steps,   s->d_st_len,
                     s->d_st_pass,    s->d_st_g1,     s->d_child_in,   s->d_child_tmp};
     for (void *b : bufs)
@@ -4496,7 +4522,7 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
     // the worklist histogram is cleared by k_prep (every path its own bins), the
     // status words by k_len_sort_block
     const bool one_block_sort = n_paths <= 32768;
-    if (!one_block_sort) {
+    if (!one_block_sort && !(cx && cx->mode == 2)) {
         HIP_TRY(hipMemsetAsync(s->d_status, 0, 8 * sizeof(uint32_t), st));
     }
     hipEvent_t *ev = s->ev[s->ev_calls % gfal_scorer::EV_RING];
@@ -4508,7 +4534,11 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
     const unsigned p_blocks = (unsigned)((n_paths + 255) / 256);
     uint32_t *const d_user_counts = d_counts;
     d_counts = s->d_counts_slot;
-    if (one_block_sort) {
+    const bool children = cx && cx->mode == 2;
+    const int32_t *const d_order = children ? nullptr : s->d_order;      // (children: slot = index)
+    if (children) {
+        // (k_child_len cleared the status words)
+    } else if (one_block_sort) {
         hipLaunchKernelGGL(k_len_sort_block, dim3(1), dim3(LEN_BINS), 0, st, d_path_off,
                            (int)n_paths, s->d_order, s->d_status, 8, nullptr, 0);
     } else {
@@ -4523,7 +4553,7 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
                        d_path_off, d_path_steps, (int)n_paths, total_steps,
                        (int)max_path_len, s->d_node_local, (int)s->n_nodes,
                        s->d_node_hist, (uint32_t)s->n_steps, s->n_empty, filter, L,
-                       s->d_order, s->d_images, d_counts, s->d_status, d_hist, s->d_lids);
+                       d_order, s->d_images, d_counts, s->d_status, d_hist, s->d_lids);
     HIP_TRY(hipGetLastError());
     if (s->profiling) HIP_TRY(hipEventRecord(ev[1], st));
 
@@ -4550,17 +4580,16 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
         if (!chain_fits || s->scan_mode == 2) n_segs2 = (int)s->segs.size();
         if (n_segs2 == 0 && !chain_fits) return GFAL_E_RANGE;
         const int item_lo_chain = n_segs2 > 0 ? (int)s->segs[(size_t)n_segs2 - 1].item_hi : 0;
-        const bool children = cx && cx->mode == 2;
         if (children) {
             // every child from its parent: the two inverted lists and the content table
             // instead of a scan over all alignments
             ChildArgs c;
             c.items = items;
-            c.ix = ChildIndex{s->d_inv_off, s->d_inv_slot, s->d_ct_key, s->d_ct_hash, s->d_ct_mult, s->ct_mask};
+            c.ix = ChildIndex{s->d_inv_off, s->d_inv_ent, s->d_ct_key, s->d_ct_hash, s->d_ct_mult, s->ct_mask};
             c.images = s->d_images;
             c.L = L;
             c.lids = s->d_lids;
-            c.order = s->d_order;
+            c.order = nullptr;
             c.n_paths = n_paths;
             c.max_aln_len = s->max_aln_len;
             c.dpass = cx->batch.dpass;
@@ -4571,7 +4600,7 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
             c.wl_capacity = s->wl_capacity;
             c.wl_hist = d_hist;
             c.status = s->d_status;
-            int chunks = std::max(1, std::min(32, 4 * s->n_cus / (int)n_paths));
+            int chunks = std::max(1, std::min(32, 8 * s->n_cus / (int)n_paths));
             if (const char *env = getenv("GFAL_CHILD_CHUNKS")) chunks = std::max(1, atoi(env));
             const size_t lds_c = img_bytes + (size_t)L.nm * sizeof(uint16_t);
             if (lds_c > (size_t)LDS_MAX - CHILD_STATIC_LDS) {
@@ -4712,9 +4741,6 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
             }
             s->last_grid += (int)grid;
         }
-        if (children)
-            hipLaunchKernelGGL(k_child_resolve, dim3(p_blocks), dim3(256), 0, st, cx->batch, s->d_order,
-                               (int)n_paths, s->n_empty, d_counts, s->d_status);
         if (cx && cx->mode == 1)      // good-without-DP, before the DP kernels add theirs
             hipLaunchKernelGGL(k_store_snapshot, dim3(p_blocks), dim3(256), 0, st, d_counts, (int)n_paths,
                                cx->d_g1_tmp);
@@ -4781,9 +4807,6 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
         HIP_TRY(hipGetLastError());
     } else {
         // a shard without alignments (zero-step ones at most): the store still follows
-        if (cx && cx->mode == 2)
-            hipLaunchKernelGGL(k_child_resolve, dim3(p_blocks), dim3(256), 0, st, cx->batch, s->d_order,
-                               (int)n_paths, s->n_empty, d_counts, s->d_status);
         if (cx && cx->mode == 1)
             hipLaunchKernelGGL(k_store_snapshot, dim3(p_blocks), dim3(256), 0, st, d_counts, (int)n_paths,
                                cx->d_g1_tmp);
@@ -4793,8 +4816,12 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
         hipLaunchKernelGGL(k_store_paths, dim3((unsigned)n_paths), dim3(256), 0, st, d_path_off, d_path_steps,
                            s->d_order, (int)n_paths, d_counts, cx->d_g1_tmp, cx->d_slots, s->d_st_steps,
                            s->d_st_len, s->d_st_pass, s->d_st_g1, s->st_cap, s->d_status);
-    hipLaunchKernelGGL(k_unpermute, dim3(p_blocks), dim3(256), 0, st, d_counts, s->d_order,
-                       (int)n_paths, d_user_counts, s->d_status, status_copy);
+    if (children)
+        hipLaunchKernelGGL(k_child_resolve, dim3(p_blocks), dim3(256), 0, st, cx->batch, (int)n_paths,
+                           s->n_empty, d_counts, d_user_counts, s->d_status, status_copy);
+    else
+        hipLaunchKernelGGL(k_unpermute, dim3(p_blocks), dim3(256), 0, st, d_counts, s->d_order,
+                           (int)n_paths, d_user_counts, s->d_status, status_copy);
     HIP_TRY(hipGetLastError());
     if (s->profiling) {
         HIP_TRY(hipEventRecord(ev[3], st));
@@ -4918,8 +4945,8 @@ static int build_child_index(gfal_scorer *s)
     } tmp{cnt, cursor};
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&cursor), (size_t)(n_loc + 1) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_inv_off), (size_t)(n_loc + 1) * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_inv_slot),
-                      std::max<size_t>((size_t)s->n_item_u16, 1) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_inv_ent),
+                      std::max<size_t>((size_t)s->n_item_u16, 1) * sizeof(uint4)));
     uint32_t slots_pow2 = 1024;
     while ((uint64_t)slots_pow2 < 2ull * std::max<uint32_t>(n_slots, 1u)) slots_pow2 <<= 1;
     s->ct_mask = slots_pow2 - 1u;
@@ -4937,10 +4964,10 @@ static int build_child_index(gfal_scorer *s)
                           s->d_item_pbase, s->n_items, s->d_item_common, s->d_item_hdr, s->d_item_weight};
         const unsigned blocks = (n_slots + 255u) / 256u;
         hipLaunchKernelGGL(k_inv_build, dim3(blocks), dim3(256), 0, st, items, s->d_slot_orig, n_slots, cnt,
-                           (uint32_t *)nullptr);
+                           (uint4 *)nullptr);
         hipLaunchKernelGGL(k_inv_scan, dim3(1), dim3(1024), 0, st, cnt, n_loc, s->d_inv_off, cursor);
         hipLaunchKernelGGL(k_inv_build, dim3(blocks), dim3(256), 0, st, items, s->d_slot_orig, n_slots, cursor,
-                           s->d_inv_slot);
+                           s->d_inv_ent);
         hipLaunchKernelGGL(k_ct_build, dim3(blocks), dim3(256), 0, st, items, s->d_slot_orig, n_slots,
                            s->d_item_hash, s->d_ct_key, s->d_ct_hash, s->d_ct_mult, s->ct_mask);
         HIP_TRY(hipGetLastError());
@@ -5044,7 +5071,7 @@ static int children_stage(gfal_scorer *s, const int32_t *parent, const int32_t *
     b.dpass = reinterpret_cast<uint32_t *>(s->d_child_tmp + 2 * (size_t)n);
     b.dg1 = reinterpret_cast<uint32_t *>(s->d_child_tmp + 3 * (size_t)n);
     hipLaunchKernelGGL(k_child_len, dim3(1), dim3(1024), 0, st, b, (int)max_len, (int)s->max_aln_len,
-                       s->d_path_off);
+                       s->d_path_off, s->d_status);
     hipLaunchKernelGGL(k_child_copy, dim3((unsigned)n), dim3(256), 0, st, b, s->d_path_off,
                        s->d_path_off + n + 1);
     HIP_TRY(hipGetLastError());
@@ -5320,13 +5347,14 @@ static int group_enqueue(gfal_group *g, const int32_t *path_off, const int32_t *
     for (size_t d = 0; d < D; ++d) {
         gfal_scorer *s = g->shards[d];
         HIP_TRY(hipSetDevice(s->device));
-        if (g->comms.empty() || d == 0)
-            HIP_TRY(hipMemcpyAsync(s->h_out, s->d_counts, n_cnt * sizeof(uint32_t), hipMemcpyDeviceToHost,
-                                   s->stream));
         // (k_unpermute put the status words behind the counters BEFORE the all-reduce
-        // touched the first 3P words)
-        HIP_TRY(hipMemcpyAsync(s->h_out + n_cnt, s->d_counts + n_cnt, 4 * sizeof(uint32_t),
-                               hipMemcpyDeviceToHost, s->stream));
+        // touched the first 3P words: one copy takes both)
+        if (g->comms.empty() || d == 0)
+            HIP_TRY(hipMemcpyAsync(s->h_out, s->d_counts, (n_cnt + 4) * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                                   s->stream));
+        else
+            HIP_TRY(hipMemcpyAsync(s->h_out + n_cnt, s->d_counts + n_cnt, 4 * sizeof(uint32_t),
+                                   hipMemcpyDeviceToHost, s->stream));
     }
     return GFAL_OK;
 }
