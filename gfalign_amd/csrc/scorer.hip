@@ -1784,7 +1784,19 @@ __device__ __forceinline__ void scan2_items(const Scan2Args &a, const Tile2 &tv,
 #endif
 }
 
-template <bool W, bool NM8>
+// G: the alignment lengths an instantiation knows -- 0: 1..4 steps, 1: 5..8 (exact
+// lengths), 2: 9..16, 3: 17..33 (pair count known, length at run time), 4: longer (steps
+// re-read from the item).  One function with the item loops of all lengths (30 instantiations) spilled
+// 93 VGPRs at the 64-register budget of 8 waves per SIMD (703 MB of scratch writes per
+// launch at config 3); a function with the loops of four lengths does not spill.  The
+// launches of one call run side by side on the scorer's side streams.
+constexpr int SCAN2_GROUPS = 5;
+constexpr int scan2_group(int M)
+{
+    return M <= 4 ? 0 : M <= 8 ? 1 : M <= 16 ? 2 : M <= 2 * MAX_REG_K + 1 ? 3 : 4;
+}
+
+template <bool W, bool NM8, int G>
 __global__ __launch_bounds__(SCAN2_THREADS, SCAN2_WAVES_PER_SIMD) void k_scan2(Scan2Args a)
 {
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
@@ -2025,26 +2037,24 @@ __global__ __launch_bounds__(SCAN2_THREADS, SCAN2_WAVES_PER_SIMD) void k_scan2(S
 #ifdef GFAL_ONLY_M      // codegen experiment: a kernel that knows one length only
         if (M == GFAL_ONLY_M) GFAL_RUN((GFAL_ONLY_M + 1) / 2, GFAL_ONLY_M);
 #else
-        if (M > 2 * MAX_REG_K + 1) {
-            GFAL_RUN(-1, 0);
-        } else {
-            switch (M) {
 #define GFAL_CASE(MM) case MM: GFAL_RUN((MM + 1) / 2, MM); break;
-                GFAL_CASE(1) GFAL_CASE(2) GFAL_CASE(3) GFAL_CASE(4)
-                GFAL_CASE(5) GFAL_CASE(6) GFAL_CASE(7) GFAL_CASE(8)
-                GFAL_CASE(9) GFAL_CASE(10) GFAL_CASE(11) GFAL_CASE(12)
+        if constexpr (G == 0) {
+            switch (M) { GFAL_CASE(1) GFAL_CASE(2) GFAL_CASE(3) GFAL_CASE(4) }
+        } else if constexpr (G == 1) {
+            switch (M) { GFAL_CASE(5) GFAL_CASE(6) GFAL_CASE(7) GFAL_CASE(8) }
+        } else if constexpr (G == 2) {
 #undef GFAL_CASE
-            default: {
-                switch ((M + 1) / 2) {           // pair dwords; M itself at run time
-#define GFAL_CASE(PP) case PP: GFAL_RUN(PP, 0); break;
-                    GFAL_CASE(7) GFAL_CASE(8) GFAL_CASE(9) GFAL_CASE(10) GFAL_CASE(11)
-                    GFAL_CASE(12) GFAL_CASE(13) GFAL_CASE(14) GFAL_CASE(15) GFAL_CASE(16)
-                    GFAL_CASE(17)
-#undef GFAL_CASE
-                }
+#define GFAL_CASE(PP) case PP: GFAL_RUN(PP, 0); break;      // pair dwords; M itself at run time
+            switch ((M + 1) / 2) { GFAL_CASE(5) GFAL_CASE(6) GFAL_CASE(7) GFAL_CASE(8) }
+        } else if constexpr (G == 3) {
+            switch ((M + 1) / 2) {
+                GFAL_CASE(9) GFAL_CASE(10) GFAL_CASE(11) GFAL_CASE(12) GFAL_CASE(13)
+                GFAL_CASE(14) GFAL_CASE(15) GFAL_CASE(16) GFAL_CASE(17)
             }
-            }
+        } else {
+            GFAL_RUN(-1, 0);
         }
+#undef GFAL_CASE
 #endif
 #undef GFAL_RUN
 #ifdef GFAL_STAMPS
@@ -3731,6 +3741,17 @@ int gfal_scorer_create_ex(const int32_t *aln_off, const int32_t *aln_steps,
                                       n_universe, 0, 1, out);
 }
 
+// k_scan2<dedup weights, byte-wide node masks, length group>
+static const void *scan2_kernel(bool w, bool nm8, int grp)
+{
+    typedef void (*kern_t)(Scan2Args);
+#define GFAL_ROW(W_, N_) {k_scan2<W_, N_, 0>, k_scan2<W_, N_, 1>, k_scan2<W_, N_, 2>, k_scan2<W_, N_, 3>, k_scan2<W_, N_, 4>}
+    static const kern_t table[2][2][SCAN2_GROUPS] = {{GFAL_ROW(false, false), GFAL_ROW(false, true)},
+                                                     {GFAL_ROW(true, false), GFAL_ROW(true, true)}};
+#undef GFAL_ROW
+    return reinterpret_cast<const void *>(table[w ? 1 : 0][nm8 ? 1 : 0][grp]);
+}
+
 static int create_impl(const int32_t *aln_off, const int32_t *aln_steps, int64_t n_aln,
                        int32_t n_nodes, int device, const int32_t *universe, int32_t n_universe,
                        int32_t shard_index, int32_t n_shards, bool dedup, gfal_scorer **out,
@@ -3942,6 +3963,18 @@ static int create_impl(const int32_t *aln_off, const int32_t *aln_steps, int64_t
                 "(pass the nodes candidate paths can visit to gfal_scorer_create_ex)",
                 n_local, MAX_LOCAL_NODES);
         return GFAL_E_RANGE;
+    }
+    {
+        // what binds first is k_prep's workgroup: the image, the node ids along the path
+        // and a 32-bit chain head per node must fit 160 KiB of LDS (~25 600 nodes)
+        const ImageLayout L = make_layout(n_local, GFAL_MAX_STEPS);
+        const size_t prep_lds = (size_t)L.total * sizeof(uint16_t) + (size_t)L.nm * sizeof(uint16_t) +
+                                (size_t)L.v2 * sizeof(uint32_t);
+        if (prep_lds > (size_t)LDS_MAX) {
+            set_err("%d distinct nodes in the alignments; the path preparation stages at most ~25 600 "
+                    "(pass the nodes candidate paths can visit to gfal_scorer_create_ex)", n_local);
+            return GFAL_E_RANGE;
+        }
     }
     std::vector<uint32_t> hist((size_t)n_local, 0);
     std::vector<uint16_t> local_steps((size_t)S);
@@ -4290,14 +4323,11 @@ static int create_impl(const int32_t *aln_off, const int32_t *aln_steps, int64_t
     CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan<true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize,
                                    LDS_BUDGET));
-    CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan2<false, false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET));
-    CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan2<true, false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET));
-    CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan2<false, true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET));
-    CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan2<true, true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET));
+    for (int w = 0; w < 2; ++w)
+        for (int nm8 = 0; nm8 < 2; ++nm8)
+            for (int grp = 0; grp < SCAN2_GROUPS; ++grp)
+                CREATE_TRY(hipFuncSetAttribute(scan2_kernel(w != 0, nm8 != 0, grp),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET));
     CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_prep),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
     if ((rc = dev_upload(&s->d_node_local, node_local))) return fail(rc);
@@ -4619,6 +4649,7 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
             s->last_lds = (int)lds_c;
         }
 
+        int scan_forks = 0;          // side streams that run a scan launch of this call
         if (n_segs2 > 0 && !children) {
             Scan2Args a2;
             a2.items = items;
@@ -4661,8 +4692,17 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
             a2.chunk_mult = (((unsigned long long)y_want << 24) + (unsigned long long)items2 - 1) /
                             (unsigned long long)std::max<int64_t>(items2, 1);
             a2.chunk_inv_min = (1ull << 24) / (unsigned long long)min_items;
-            for (int s0 = 0; s0 < n_segs2; s0 += MAX_SEGS) {
-                const int ns = std::min(MAX_SEGS, n_segs2 - s0);
+            // one launch per run of segments of one length group (the lengths ascend: as
+            // many runs as groups that occur), side by side: the first on the caller's stream, the others on
+            // the side streams the DP kernels use later
+            int n_launch = 0;
+            int &joined = scan_forks;
+            for (int s0 = 0; s0 < n_segs2;) {
+                const int grp = scan2_group((int)s->segs[(size_t)s0].m);
+                int ns = 1;
+                while (s0 + ns < n_segs2 && ns < MAX_SEGS &&
+                       scan2_group((int)s->segs[(size_t)(s0 + ns)].m) == grp)
+                    ++ns;
                 a2.segs = s->d_segs + s0;
                 a2.n_segs = ns;
                 unsigned y_total = 0;
@@ -4671,16 +4711,23 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
                     y_total += seg_chunks(sg.item_hi - sg.item_lo, a2.chunk_mult, a2.chunk_inv_min);
                 }
                 const unsigned grid2 = (unsigned)a2.n_tiles * y_total;
-                if (s->d_item_weight) {
-                    if (nm8) hipLaunchKernelGGL((k_scan2<true, true>), dim3(grid2), dim3(SCAN2_THREADS), lds2, st, a2);
-                    else hipLaunchKernelGGL((k_scan2<true, false>), dim3(grid2), dim3(SCAN2_THREADS), lds2, st, a2);
-                } else {
-                    if (nm8) hipLaunchKernelGGL((k_scan2<false, true>), dim3(grid2), dim3(SCAN2_THREADS), lds2, st, a2);
-                    else hipLaunchKernelGGL((k_scan2<false, false>), dim3(grid2), dim3(SCAN2_THREADS), lds2, st, a2);
+                hipStream_t on = st;
+                static const bool serial = getenv("GFAL_SCAN2_SERIAL") != nullptr;      // (measurements)
+                if (n_launch > 0 && !serial) {
+                    const int side = (n_launch - 1) % 3;
+                    if (n_launch == 1) HIP_TRY(hipEventRecord(s->dp_fork, st));
+                    if (!(joined & (1 << side))) HIP_TRY(hipStreamWaitEvent(s->dp_stream[side], s->dp_fork, 0));
+                    joined |= 1 << side;
+                    on = s->dp_stream[side];
                 }
-                HIP_TRY(hipGetLastError());
+                void *kargs[] = {&a2};
+                HIP_TRY(hipLaunchKernel(scan2_kernel(s->d_item_weight != nullptr, nm8, grp), dim3(grid2),
+                                        dim3(SCAN2_THREADS), kargs, lds2, on));
                 s->last_grid += (int)grid2;
+                ++n_launch;
+                s0 += ns;
             }
+
             s->last_tile = tile;
             s->last_lds = (int)lds2;
         }
@@ -4741,6 +4788,11 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
             }
             s->last_grid += (int)grid;
         }
+        for (int i = 0; i < 3; ++i)      // the scan launches on the side streams are done
+            if (scan_forks & (1 << i)) {
+                HIP_TRY(hipEventRecord(s->dp_join[i], s->dp_stream[i]));
+                HIP_TRY(hipStreamWaitEvent(st, s->dp_join[i], 0));
+            }
         if (cx && cx->mode == 1)      // good-without-DP, before the DP kernels add theirs
             hipLaunchKernelGGL(k_store_snapshot, dim3(p_blocks), dim3(256), 0, st, d_counts, (int)n_paths,
                                cx->d_g1_tmp);

@@ -21,6 +21,9 @@ say valu_rate; ./tools/valu_rate > gpurun_out/valu_rate_${tag}.jsonl 2> /dev/nul
   echo "## candidate batches of the search itself (scripts/search_batch.py config3 10000 20000 <skip>)"
   python3 scripts/search_batch.py config3 10000 20000 0; python3 scripts/search_batch.py config3 10000 20000 50000
   echo "## gfalign search end to end (scripts/e2e_search.py config3 20000 32,128,512)"; python3 scripts/e2e_search.py config3 20000 32,128,512
+  echo "## gfalign search -m 20000, candidates from their parents (default) and in full (scripts/e2e_incr.sh)"
+  bash scripts/e2e_incr.sh config3 20000 128 2>&1 | cut -c1-260; bash scripts/e2e_incr.sh config5 20000 128 2>&1 | cut -c1-260
+  echo "## one rank's share of an N-GPU run (scripts/shard_curve.py config3)"; python3 scripts/shard_curve.py config3 2>&1 | grep alignments
   echo "## one rank's share of 8 (scripts/shard_probe.py 8 8192)"; python3 scripts/shard_probe.py 8 8192 2>&1 | grep shard
   echo "## config 5, one GPU (scripts/scan_probe.py config5)"; python3 scripts/scan_probe.py config5 "" "GFAL_SCAN=1" 2>&1 | grep -v amdgpu.ids
 } > gpurun_out/workloads_${tag}.txt 2>&1

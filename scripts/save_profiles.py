@@ -25,8 +25,12 @@ def summ(d):
             n = kernel_key(r["Kernel_Name"])
             if n:
                 acc[n][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        # a bench step launches k_prep once, k_scan2 once per alignment-length group that
+        # occurs and k_scan once: per-step figures are sums over a step's dispatches
+        steps = max([len(v) for v in acc.get("k_prep", {}).values()] + [1])
         for n, c in acc.items():
-            out[n] = {k: {"mean_per_dispatch": sum(v) / len(v), "dispatches": len(v)}
+            out[n] = {k: {"mean_per_dispatch": sum(v) / len(v), "dispatches": len(v),
+                          "per_step": sum(v) / steps}
                       for k, v in c.items()}
     return out
 
@@ -48,17 +52,50 @@ pmc = {
 json.dump(pmc, open("profiles/%s_pmc_config3.json" % tag, "w"), indent=1)
 
 
+def scan_span():
+    """The scan kernels of one step run side by side (k_scan2 once per alignment-length
+    group on its own stream, k_scan): what compares with bench.py's live `kernel_ms` is
+    the span from the first start to the last end, per step, from the kernel trace of
+    the --stats run; the per-kernel durations in the stats table overlap."""
+    tr = sorted(glob.glob("gpurun_out/prof_%s_stats/*/*_kernel_trace.csv" % tag), key=os.path.getmtime)[-1]
+    rows = sorted((r for r in csv.DictReader(open(tr))), key=lambda r: int(r["Start_Timestamp"]))
+    spans, busy, cur = [], [], None
+    for r in rows:
+        k = kernel_key(r["Kernel_Name"])
+        if k == "k_prep":
+            cur = [None, None, 0]
+        elif k in ("k_scan2", "k_scan") and cur is not None:
+            s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+            cur[0] = s if cur[0] is None else min(cur[0], s)
+            cur[1] = e if cur[1] is None else max(cur[1], e)
+            cur[2] += e - s
+        elif k == "k_wl_offsets" and cur is not None and cur[0] is not None:
+            spans.append(cur[1] - cur[0])
+            busy.append(cur[2])
+            cur = None
+    return {"steps": len(spans), "scan_span_us_mean": sum(spans) / len(spans) / 1e3,
+            "scan_span_us_min": min(spans) / 1e3, "scan_span_us_max": max(spans) / 1e3,
+            "sum_of_kernel_durations_us_mean": sum(busy) / len(busy) / 1e3,
+            "source": "kernel trace of `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 3 "
+                      "--no-cpu-baseline --no-search-mode` (scripts/collect_profiles.sh)"}
+
+
+span = scan_span()
+json.dump(span, open("profiles/%s_scan_span.json" % tag, "w"), indent=1)
+print(json.dumps(span, indent=1))
+
+
 def per_step(group, counter):
-    """sum over the two scan kernels of one bench step (each is launched once per step)"""
+    """sum over the scan kernels' dispatches of one bench step"""
     tot = 0.0
     for k in ("k_scan2", "k_scan"):
-        tot += pmc[group].get(k, {}).get(counter, {}).get("mean_per_dispatch", 0.0)
+        tot += pmc[group].get(k, {}).get(counter, {}).get("per_step", 0.0)
     return tot
 
 
 fetch, write = per_step("FETCH_SIZE", "FETCH_SIZE"), per_step("WRITE_SIZE", "WRITE_SIZE")
 traffic = {
-    "workload": "config3", "kernels": "k_scan2 + k_scan (one launch each per step)",
+    "workload": "config3", "kernels": "k_scan2 (one launch per alignment-length group) + k_scan, summed per step",
     "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write,
     "hbm_bytes_per_launch": int(fetch * 1024 * 2 + write * 1024),
     "method": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over bench.py; read side "
@@ -68,7 +105,7 @@ traffic = {
     "source": "profiles/%s_pmc_config3.json" % tag}
 json.dump(traffic, open("profiles/traffic_config3.json", "w"), indent=1)
 issue = {
-    "workload": "config3", "kernels": "k_scan2 + k_scan (one launch each per step)",
+    "workload": "config3", "kernels": "k_scan2 (one launch per alignment-length group) + k_scan, summed per step",
     "valu_wave_insts_per_step": per_step("SQ_1", "SQ_INSTS_VALU"),
     "salu_wave_insts_per_step": per_step("SQ_1", "SQ_INSTS_SALU"),
     "lds_wave_insts_per_step": per_step("SQ_1", "SQ_INSTS_LDS"),

@@ -158,13 +158,14 @@ def test_dedup_and_shards_through_k_scan2(gpu, monkeypatch):
         assert np.array_equal(a, e.astype(np.uint64))
 
 
-def test_many_nodes_need_no_chain_images(gpu):
-    """15 000 nodes: k_scan's path images (a first-occurrence table per node) no
-    longer fit the LDS; k_scan2 only keeps node masks per node and takes every
-    length.  (Round 1 answered GFAL_E_RANGE above ~11 000 nodes; the reference
-    has no limit, include/nodetable.h:11-43.)"""
+@pytest.mark.parametrize("n_nodes", [15000, 24000])
+def test_many_nodes_need_no_chain_images(gpu, n_nodes):
+    """15 000 / 24 000 nodes: k_scan's path images (a first-occurrence table per
+    node) no longer fit the LDS; k_scan2 only keeps node masks per node and takes
+    every length.  (Round 1 answered GFAL_E_RANGE above ~11 000 nodes; the reference
+    has no limit, include/nodetable.h:11-43; this build's is ~25 600 nodes inside the
+    tangle, refused at create.)"""
     rnd = random.Random(71)
-    n_nodes = 15000
     walk = [(v << 1) | rnd.randrange(2) for v in rnd.sample(range(n_nodes), n_nodes)]
     paths = [walk[s:s + rnd.randint(50, 600)] for s in (rnd.randrange(0, n_nodes - 600) for _ in range(100))]
     alns = []
@@ -181,7 +182,7 @@ def test_many_nodes_need_no_chain_images(gpu):
     aoff, ast = csr(alns)
     poff, pst = csr(paths)
     with Scorer(aoff, ast, n_nodes) as sc:
-        assert sc.info()["n_local_nodes"] >= 14000
+        assert sc.info()["n_local_nodes"] >= n_nodes - 1000
         got = sc.evaluate_paths(poff, pst, True)
         few = sc.evaluate_paths(poff[:9], pst[:poff[8]], True)     # a small batch as well
     exp = oracle.evaluate_paths(aoff, ast, poff, pst, True)
