@@ -353,7 +353,7 @@ def main():
             },
             "roofline": {
                 "bound": "valu-issue",
-                "kernel": "k_scan2 (+ k_scan for the rare alignment lengths)",
+                "kernel": "k_scan2 (one launch per alignment-length group, side by side) + k_scan (rare lengths): span from the first start to the last end",
                 "achieved": achieved,
                 "peak": peak,
                 "unit": "G wave-instructions/s",

@@ -1788,8 +1788,10 @@ __device__ __forceinline__ void scan2_items(const Scan2Args &a, const Tile2 &tv,
 // lengths), 2: 9..16, 3: 17..33 (pair count known, length at run time), 4: longer (steps
 // re-read from the item).  One function with the item loops of all lengths (30 instantiations) spilled
 // 93 VGPRs at the 64-register budget of 8 waves per SIMD (703 MB of scratch writes per
-// launch at config 3); a function with the loops of four lengths does not spill.  The
-// launches of one call run side by side on the scorer's side streams.
+// launch at config 3); a function with the loops of four lengths does not spill.
+// G == SCAN2_GROUPS is that one function: a batch of a few thousand paths is better off
+// with one launch that spills than with several that each end in a tail of prologues
+// (2048 paths: 1.36 against 1.52 ms per call); from 4096 paths on the split ones run.
 constexpr int SCAN2_GROUPS = 5;
 constexpr int scan2_group(int M)
 {
@@ -2037,23 +2039,25 @@ __global__ __launch_bounds__(SCAN2_THREADS, SCAN2_WAVES_PER_SIMD) void k_scan2(S
 #ifdef GFAL_ONLY_M      // codegen experiment: a kernel that knows one length only
         if (M == GFAL_ONLY_M) GFAL_RUN((GFAL_ONLY_M + 1) / 2, GFAL_ONLY_M);
 #else
+        constexpr bool ALL = G == SCAN2_GROUPS;       // the instantiation that knows every length
+        const int grp = scan2_group(M);
 #define GFAL_CASE(MM) case MM: GFAL_RUN((MM + 1) / 2, MM); break;
-        if constexpr (G == 0) {
-            switch (M) { GFAL_CASE(1) GFAL_CASE(2) GFAL_CASE(3) GFAL_CASE(4) }
-        } else if constexpr (G == 1) {
-            switch (M) { GFAL_CASE(5) GFAL_CASE(6) GFAL_CASE(7) GFAL_CASE(8) }
-        } else if constexpr (G == 2) {
+        if constexpr (ALL || G == 0)
+            if (grp == 0) switch (M) { GFAL_CASE(1) GFAL_CASE(2) GFAL_CASE(3) GFAL_CASE(4) }
+        if constexpr (ALL || G == 1)
+            if (grp == 1) switch (M) { GFAL_CASE(5) GFAL_CASE(6) GFAL_CASE(7) GFAL_CASE(8) }
 #undef GFAL_CASE
 #define GFAL_CASE(PP) case PP: GFAL_RUN(PP, 0); break;      // pair dwords; M itself at run time
-            switch ((M + 1) / 2) { GFAL_CASE(5) GFAL_CASE(6) GFAL_CASE(7) GFAL_CASE(8) }
-        } else if constexpr (G == 3) {
-            switch ((M + 1) / 2) {
-                GFAL_CASE(9) GFAL_CASE(10) GFAL_CASE(11) GFAL_CASE(12) GFAL_CASE(13)
-                GFAL_CASE(14) GFAL_CASE(15) GFAL_CASE(16) GFAL_CASE(17)
-            }
-        } else {
-            GFAL_RUN(-1, 0);
-        }
+        if constexpr (ALL || G == 2)
+            if (grp == 2) switch ((M + 1) / 2) { GFAL_CASE(5) GFAL_CASE(6) GFAL_CASE(7) GFAL_CASE(8) }
+        if constexpr (ALL || G == 3)
+            if (grp == 3)
+                switch ((M + 1) / 2) {
+                    GFAL_CASE(9) GFAL_CASE(10) GFAL_CASE(11) GFAL_CASE(12) GFAL_CASE(13)
+                    GFAL_CASE(14) GFAL_CASE(15) GFAL_CASE(16) GFAL_CASE(17)
+                }
+        if constexpr (ALL || G == 4)
+            if (grp == 4) GFAL_RUN(-1, 0);
 #undef GFAL_CASE
 #endif
 #undef GFAL_RUN
@@ -2387,7 +2391,8 @@ __global__ __launch_bounds__(256) void k_wl_scatter(
     const unsigned long long *__restrict__ wl_count, uint32_t wl_capacity,
     const uint32_t *__restrict__ offsets, uint32_t *__restrict__ cursor,
     uint32_t n_paths, unsigned long long *__restrict__ sorted,
-    const uint32_t *__restrict__ class_total, uint32_t *__restrict__ class_lo)
+    const uint32_t *__restrict__ class_total, uint32_t *__restrict__ class_lo,
+    const uint32_t *__restrict__ wl_pos, uint32_t *__restrict__ sorted_pos)
 {
     // overflow (status word set by k_scan): the histogram counted pairs that
     // were never stored, so offsets do not describe the list; the call fails
@@ -2434,7 +2439,10 @@ __global__ __launch_bounds__(256) void k_wl_scatter(
             base = atomicAdd(&cursor[bin], (uint32_t)__builtin_popcountll(run));
         base = (uint32_t)__shfl((int)base, head, WAVE);
         const uint32_t at = live ? my_base + offsets[bin] + base + (uint32_t)(lane - head) : 0u;
-        if (live) sorted[at] = ent;
+        if (live) {
+            sorted[at] = ent;
+            if (wl_pos) sorted_pos[at] = wl_pos[w];
+        }
     }
 }
 
@@ -2458,9 +2466,17 @@ struct DpArgs {
     uint32_t sys_limit;         // see wavefront_class()
     uint32_t *row_scratch;
     uint32_t *counts;
+    // search mode (children batches; else NULL): where an entry sits in the inverted
+    // list of its path's first node, and the per-path bitmaps over that list in the
+    // store that remember which entries the DP accepted (k_child inherits them)
+    const uint32_t *sorted_pos;
+    uint32_t *bits;
+    uint32_t bits_words;
+    const int32_t *q_slot;      // image slot -> store slot or -1
 };
 
 struct DpEntry {
+    uint32_t pos;
     uint32_t p;
     const uint16_t *astep, *bp;
     int n, m;
@@ -2483,6 +2499,7 @@ __device__ __forceinline__ DpEntry load_entry(const DpArgs &a, uint32_t w, bool 
     e.has_fw = (ent & WL_FW) != 0;
     e.has_rc = (ent & WL_RC) != 0;
     e.w = (live && a.items.weight) ? a.items.weight[slot] : 1u;
+    e.pos = (live && a.sorted_pos) ? a.sorted_pos[w] : 0u;
     return e;
 }
 
@@ -2508,8 +2525,12 @@ __device__ __forceinline__ bool wavefront_class(const DpArgs &a, uint32_t total,
 // lane -- all resident waves work on the same few paths at a time, and per-lane
 // atomics on those few words were 75 % of the DP phase.
 __device__ __forceinline__ void add_results_by_path(const DpArgs &a, uint32_t p, bool live,
-                                                    bool good, int lane, uint32_t w = 1u)
+                                                    bool good, int lane, uint32_t w = 1u, uint32_t pos = 0u)
 {
+    if (a.bits != nullptr && live && good) {       // search mode: remembered for the path's children
+        const int slot = a.q_slot[p];
+        if (slot >= 0) atomicOr(&a.bits[(size_t)slot * a.bits_words + (pos >> 5)], 1u << (pos & 31u));
+    }
     const uint32_t prev_p = (uint32_t)__shfl_up((int)p, 1, WAVE);
     const lanemask live_mask = WAVE_MASK(live), good_mask = WAVE_MASK(good && live);
     // a run starts at a live lane whose left neighbour is dead or on another path
@@ -2603,7 +2624,7 @@ __global__ __launch_bounds__(DP_THREADS) void k_dp_regs(DpArgs a)
 #if defined(GFAL_ABLATE) && GFAL_ABLATE == 3
         good = false;
 #endif
-        add_results_by_path(a, e.p, live, good, lane, e.w);
+        add_results_by_path(a, e.p, live, good, lane, e.w, e.pos);
     }
 }
 
@@ -2822,7 +2843,7 @@ __global__ __launch_bounds__(DP_THREADS) void k_dp_sys(DpArgs a)
         const lanemask gm = WAVE_MASK(good);
         const lanemask mine = (gm >> (lane / SPAN * SPAN)) & (SPAN == 64 ? ~0ull : ((1ull << SPAN) - 1ull));
         // one result per entry, carried by the first lane of its span
-        add_results_by_path(a, e.p, live && lane % SPAN == 0, mine != 0, lane, e.w);
+        add_results_by_path(a, e.p, live && lane % SPAN == 0, mine != 0, lane, e.w, e.pos);
     }
 }
 
@@ -2851,7 +2872,7 @@ __global__ __launch_bounds__(DP_THREADS) void k_dp_long(DpArgs a)
         B.flip = 1u;
         const int rc = traceback_score(A, B, row, stride);
         const bool good = fw == 0 || rc == 0;
-        add_results_by_path(a, e.p, mine, good, (int)threadIdx.x, e.w);
+        add_results_by_path(a, e.p, mine, good, (int)threadIdx.x, e.w, e.pos);
     }
 }
 
@@ -3030,6 +3051,9 @@ struct ChildBatch {
     int64_t st_cap;
     int32_t *root, *depth;   // [n] scratch: stored ancestor, steps beyond it
     uint32_t *dpass, *dg1;   // [n] scratch: the child's own deltas
+    uint32_t *st_bits;       // [cap][bits_words] entries of the first node's list the DP accepted
+    int32_t *st_bitsok;      // [cap] the bitmap is valid (NULL / 0 words: nothing is remembered)
+    uint32_t bits_words;
 };
 
 // lengths and offsets of the batch's paths (one workgroup)
@@ -3140,6 +3164,8 @@ struct ChildArgs {
     const int32_t *order;      // image slot -> child index
     int n_paths, max_aln_len;
     uint32_t *dpass, *dg1;     // by child index
+    ChildBatch b;              // roots, depths, slots, the store's bitmaps
+    uint32_t *wl_pos;          // list position of every pushed entry (NULL: nothing is remembered)
     uint32_t *counts;          // by image slot: bad | good | unaligned
     unsigned long long *worklist;
     unsigned long long *wl_count;
@@ -3178,7 +3204,7 @@ __device__ __forceinline__ uint32_t ct_lookup(const ChildArgs &a, uint32_t h, in
 constexpr int CHILD_WAVES = CHILD_THREADS / WAVE;
 constexpr int CHILD_STAGE_PAIRS = 16;
 constexpr int CHILD_WL_BUF = 1024;             // worklist entries a workgroup gathers before it appends them
-constexpr int CHILD_STATIC_LDS = CHILD_WAVES * CHILD_STAGE_PAIRS * WAVE * 4 + CHILD_WL_BUF * 8 + 256;
+constexpr int CHILD_STATIC_LDS = CHILD_WAVES * CHILD_STAGE_PAIRS * WAVE * 4 + CHILD_WL_BUF * 12 + 256;
 
 template <bool W>
 __global__ __launch_bounds__(CHILD_THREADS) void k_child(ChildArgs a)
@@ -3187,6 +3213,7 @@ __global__ __launch_bounds__(CHILD_THREADS) void k_child(ChildArgs a)
     __shared__ uint32_t red[4];     // Lmax | node seen before
     __shared__ uint32_t stage[CHILD_WAVES][CHILD_STAGE_PAIRS][WAVE];
     __shared__ unsigned long long wl_buf[CHILD_WL_BUF];
+    __shared__ uint32_t wl_at[CHILD_WL_BUF];
     __shared__ uint32_t wl_n, wl_cls[N_CLASSES], wl_base[2];
     uint16_t *img = smem;
     uint16_t *lid = smem + a.L.total;
@@ -3302,10 +3329,30 @@ __global__ __launch_bounds__(CHILD_THREADS) void k_child(ChildArgs a)
             if (pass) newpass += W ? a.items.weight[slot] : 1u;
         }
     }
-    // start-overhang candidates: alignments that carry the path's first node, one DP
-    // length class after the other (the worklist sort wants runs of one class).  They
-    // are gathered in LDS and leave the workgroup with ONE atomic on the list cursor
-    // (an atomic per wave and round on that one word was 90 % of this kernel).
+    // Start-overhang candidates: the alignments that carry the path's first node.  What
+    // the exact DP said about one of them for the stored ancestor still holds for this
+    // path if none of its nodes is on the path's last Mmax + depth steps: the rows in
+    // between only subtract, the table was in its steady state at the ancestor and stays
+    // there, and no new node or window concerns the alignment (tests/incr_model.py,
+    // inherits()).  The ancestor's verdicts sit in a bitmap over the list; this path's
+    // own bitmap takes the inherited bits here and the rest from the DP kernels.
+    // Candidates that are not inherited are gathered in LDS and leave the workgroup
+    // with ONE atomic on the list cursor (an atomic per wave and round on that one word
+    // was 90 % of the first version of this kernel).
+    const bool remember = a.wl_pos != nullptr;
+    const int root = a.b.root[child], my_slot = a.b.slot[child];
+    const bool can_inherit = remember && root >= 0 && a.b.st_bitsok[root] != 0;
+    uint32_t *tail = reinterpret_cast<uint32_t *>(lid + a.L.nm);      // [v2 / 32] nodes of the path's tail
+    if (can_inherit) {
+        for (int i = tid; i < (a.L.v2 + 31) / 32; i += CHILD_THREADS) tail[i] = 0;
+        __syncthreads();
+        const int from = max(0, n - (a.max_aln_len + a.b.depth[child]));
+        for (int p = from + tid; p < n; p += CHILD_THREADS) {
+            const uint32_t v = lds_u16(lid32, (uint32_t)p);
+            if (v != ENT_NONE) atomicOr(&tail[v >> 5], 1u << (v & 31u));
+        }
+        __syncthreads();
+    }
     auto flush = [&]() {            // (every thread of the workgroup calls it)
         __syncthreads();
         const uint32_t cnt = wl_n;
@@ -3324,8 +3371,12 @@ __global__ __launch_bounds__(CHILD_THREADS) void k_child(ChildArgs a)
             const unsigned long long base = ((unsigned long long)wl_base[1] << 32) | wl_base[0];
             bool over = false;
             for (uint32_t i = (uint32_t)tid; i < cnt; i += CHILD_THREADS) {
-                if (base + i < a.wl_capacity) a.worklist[base + i] = wl_buf[i];
-                else over = true;
+                if (base + i < a.wl_capacity) {
+                    a.worklist[base + i] = wl_buf[i];
+                    if (remember) a.wl_pos[base + i] = wl_at[i];
+                } else {
+                    over = true;
+                }
             }
             if (over) atomicOr(a.status, ST_DP_OVERFLOW);
             __syncthreads();
@@ -3333,80 +3384,99 @@ __global__ __launch_bounds__(CHILD_THREADS) void k_child(ChildArgs a)
         }
         __syncthreads();
     };
+    uint32_t inh_good = 0;
     if (a0 != STEP_NOMATCH && a0_lid != ENT_NONE) {
-        for (int cls = 0; cls < N_CLASSES; ++cls) {
-            const uint32_t lo = a.ix.inv_off[a0_lid * N_CLASSES + (uint32_t)cls];
-            const uint32_t hi = a.ix.inv_off[a0_lid * N_CLASSES + (uint32_t)cls + 1u];
-            for (uint32_t e0 = lo + (uint32_t)chunk * CHILD_THREADS; e0 < hi; e0 += stride) {
-                const uint32_t e = e0 + (uint32_t)tid;
-                bool fw = false, rc = false;
-                uint32_t slot = 0;
-                int m = 0;
-                if (e < hi) {
-                    const uint4 ent = a.ix.inv_ent[e];
-                    slot = ent.x;
-                    m = load_B(ent);
-                    if (m >= 2 && m <= n) {
-                        // a proper suffix of B (of rc(B)) equals a prefix of the path
-                        for (int t = 1; t < m && !fw; ++t)
-                            if (B(t) == a0) {
-                                bool eq = true;
-                                for (int k = 1; k < m - t && eq; ++k) eq = B(t + k) == stepA(k);
-                                fw = eq;
-                            }
-                        for (int t = 0; t + 1 < m && !rc; ++t)
-                            if ((B(t) ^ 1u) == a0) {
-                                bool eq = true;
-                                for (int k = 1; k <= t && eq; ++k) eq = (B(t - k) ^ 1u) == stepA(k);
-                                rc = eq;
-                            }
-                    }
+        const uint32_t list_lo = a.ix.inv_off[a0_lid * N_CLASSES], list_hi = a.ix.inv_off[(a0_lid + 1u) * N_CLASSES];
+        const uint32_t *pbits = can_inherit ? a.b.st_bits + (size_t)root * a.b.bits_words : nullptr;
+        uint32_t *cbits = (remember && my_slot >= 0) ? a.b.st_bits + (size_t)my_slot * a.b.bits_words : nullptr;
+        for (uint32_t e0 = list_lo + (uint32_t)chunk * CHILD_THREADS; e0 < list_hi; e0 += stride) {
+            const uint32_t ew = e0 + (uint32_t)(tid & ~(WAVE - 1));     // the wave's 64 list positions:
+            const uint32_t e = ew + (uint32_t)lane;                     // (ew - list_lo) is a multiple of 64
+            const uint32_t pos = e - list_lo;
+            bool fw = false, rc = false, inh_bit = false;
+            uint32_t slot = 0;
+            int m = 0;
+            if (e < list_hi) {
+                const uint4 ent = a.ix.inv_ent[e];
+                slot = ent.x;
+                m = load_B(ent);
+                bool inherit = can_inherit;
+                for (int t = 0; t < m && inherit; ++t) {
+                    const uint32_t v = B(t) >> 1;
+                    inherit = ((tail[v >> 5] >> (v & 31u)) & 1u) == 0u;
                 }
-                if (fw || rc) {
-                    bool pass = true;      // the filter (src/eval.cpp:81-91)
-                    for (int t = 0; t < m && pass; ++t) pass = on_path(B(t));
-                    bool found = false;    // a subpath on either strand is good without the DP
-                    if (pass) {
-                        uint32_t ent = lds_u16(first32, b0 >> 1);
-                        while ((ent & 0x7C00u) == 0u && !found) {
-                            const int pos = (int)(ent & ENT_POS);
-                            const bool neg = (ent & ENT_NEG) != 0u;
-                            bool eq = false;
-                            if (neg == ((b0 & 1u) != 0u)) {
-                                if (pos + m <= n) {
-                                    eq = true;
-                                    for (int t = 1; t < m && eq; ++t) eq = stepA(pos + t) == B(t);
-                                }
-                            } else if (pos >= m - 1) {
-                                eq = true;
-                                for (int t = 1; t < m && eq; ++t) eq = stepA(pos - t) == (B(t) ^ 1u);
-                            }
-                            found = eq;
-                            ent = next[pos];
+                if (inherit) {
+                    inh_bit = ((pbits[pos >> 5] >> (pos & 31u)) & 1u) != 0u;
+                } else if (m >= 2 && m <= n) {
+                    // a proper suffix of B (of rc(B)) equals a prefix of the path
+                    for (int t = 1; t < m && !fw; ++t)
+                        if (B(t) == a0) {
+                            bool eq = true;
+                            for (int k = 1; k < m - t && eq; ++k) eq = B(t + k) == stepA(k);
+                            fw = eq;
                         }
-                    }
-                    if (!pass || found) fw = rc = false;
+                    for (int t = 0; t + 1 < m && !rc; ++t)
+                        if ((B(t) ^ 1u) == a0) {
+                            bool eq = true;
+                            for (int k = 1; k <= t && eq; ++k) eq = (B(t - k) ^ 1u) == stepA(k);
+                            rc = eq;
+                        }
                 }
-                const bool want = fw || rc;
-                const lanemask wm = WAVE_MASK(want);
-                if (wm != 0ull) {
-                    const int leader = __builtin_ctzll(wm);
-                    uint32_t at = 0;
-                    if (lane == leader) {
-                        const uint32_t cnt = (uint32_t)__builtin_popcountll(wm);
-                        at = atomicAdd(&wl_n, cnt);
-                        atomicAdd(&wl_cls[cls], cnt);
-                    }
-                    at = (uint32_t)__builtin_amdgcn_readlane((int)at, leader);
-                    if (want) {
-                        wl_buf[at + lanes_below(wm, lane)] = (fw ? WL_FW : 0ull) | (rc ? WL_RC : 0ull) |
-                                                              ((unsigned long long)(uint32_t)q << 32) | slot;
-                        ncand += W ? a.items.weight[slot] : 1u;
-                    }
-                }
-                __syncthreads();
-                if (wl_n > (uint32_t)(CHILD_WL_BUF - CHILD_THREADS)) flush();     // (the same for every thread)
             }
+            if (fw || rc) {
+                bool pass = true;      // the filter (src/eval.cpp:81-91)
+                for (int t = 0; t < m && pass; ++t) pass = on_path(B(t));
+                bool found = false;    // a subpath on either strand is good without the DP
+                if (pass) {
+                    uint32_t ent = lds_u16(first32, b0 >> 1);
+                    while ((ent & 0x7C00u) == 0u && !found) {
+                        const int pos_a = (int)(ent & ENT_POS);
+                        const bool neg = (ent & ENT_NEG) != 0u;
+                        bool eq = false;
+                        if (neg == ((b0 & 1u) != 0u)) {
+                            if (pos_a + m <= n) {
+                                eq = true;
+                                for (int t = 1; t < m && eq; ++t) eq = stepA(pos_a + t) == B(t);
+                            }
+                        } else if (pos_a >= m - 1) {
+                            eq = true;
+                            for (int t = 1; t < m && eq; ++t) eq = stepA(pos_a - t) == (B(t) ^ 1u);
+                        }
+                        found = eq;
+                        ent = next[pos_a];
+                    }
+                }
+                if (!pass || found) fw = rc = false;
+            }
+            // this path's bitmap: the wave's 64 positions are two whole words of it
+            const lanemask im = WAVE_MASK(inh_bit);
+            if (cbits && ew < list_hi && lane < 2) {
+                const uint32_t word = ((ew - list_lo) >> 5) + (uint32_t)lane;
+                if (word < a.b.bits_words) cbits[word] = (uint32_t)(im >> (32 * lane));
+            }
+            if (inh_bit) inh_good += W ? a.items.weight[slot] : 1u;
+            const bool want = fw || rc;
+            const lanemask wm = WAVE_MASK(want);
+            if (wm != 0ull) {
+                const int leader = __builtin_ctzll(wm);
+                const int cls = length_class(m);
+                uint32_t at = 0;
+                if (lane == leader) at = atomicAdd(&wl_n, (uint32_t)__builtin_popcountll(wm));
+                at = (uint32_t)__builtin_amdgcn_readlane((int)at, leader);
+                for (int c = 0; c < N_CLASSES; ++c) {      // (the list is ordered by class: one or two per wave)
+                    const lanemask mc = WAVE_MASK(want && cls == c);
+                    if (mc != 0ull && lane == __builtin_ctzll(mc))
+                        atomicAdd(&wl_cls[c], (uint32_t)__builtin_popcountll(mc));
+                }
+                if (want) {
+                    const uint32_t k = at + lanes_below(wm, lane);
+                    wl_buf[k] = (fw ? WL_FW : 0ull) | (rc ? WL_RC : 0ull) | ((unsigned long long)(uint32_t)q << 32) | slot;
+                    wl_at[k] = pos;
+                    ncand += W ? a.items.weight[slot] : 1u;
+                }
+            }
+            __syncthreads();
+            if (wl_n > (uint32_t)(CHILD_WL_BUF - CHILD_THREADS)) flush();     // (the same for every thread)
         }
     }
     flush();
@@ -3416,11 +3486,14 @@ __global__ __launch_bounds__(CHILD_THREADS) void k_child(ChildArgs a)
         hits += __shfl_down(hits, o, WAVE);
         newpass += __shfl_down(newpass, o, WAVE);
         ncand += __shfl_down(ncand, o, WAVE);
+        inh_good += __shfl_down(inh_good, o, WAVE);
     }
     if (lane == 0) {
         if (hits) atomicAdd(&a.dg1[child], hits);
         if (newpass) atomicAdd(&a.dpass[child], newpass);
-        if (ncand) atomicSub(&a.counts[q], ncand);
+        // (inherited verdicts: the accepted ones move from bad to good right here)
+        if (ncand + inh_good) atomicSub(&a.counts[q], ncand + inh_good);
+        if (inh_good) atomicAdd(&a.counts[a.n_paths + q], inh_good);
     }
 }
 
@@ -3451,6 +3524,7 @@ __global__ void k_child_resolve(ChildBatch b, int n_paths, uint32_t n_empty,
         if (slot >= 0) {
             b.st_pass[slot] = pass;
             b.st_g1[slot] = g1;
+            if (b.bits_words) b.st_bitsok[slot] = 1;     // k_child + the DP kernels filled it
         }
     }
     out[q] = counts[q] + (pass - g1);
@@ -3474,7 +3548,8 @@ __global__ __launch_bounds__(256) void k_store_paths(const int32_t *__restrict__
                                                      const uint32_t *__restrict__ g1_tmp,
                                                      const int32_t *__restrict__ slots, int32_t *st_steps,
                                                      int32_t *st_len, uint32_t *st_pass, uint32_t *st_g1,
-                                                     int64_t st_cap, uint32_t *__restrict__ status)
+                                                     int32_t *st_bitsok, int64_t st_cap,
+                                                     uint32_t *__restrict__ status)
 {
     const int q = blockIdx.x, tid = threadIdx.x;
     const int i = order[q];
@@ -3492,6 +3567,7 @@ __global__ __launch_bounds__(256) void k_store_paths(const int32_t *__restrict__
         st_len[slot] = L;
         st_pass[slot] = counts[q] + counts[n_paths + q];
         st_g1[slot] = g1_tmp[q];
+        if (st_bitsok) st_bitsok[slot] = 0;     // (the scan kernels do not know list positions)
     }
 }
 }  // namespace
@@ -3580,6 +3656,13 @@ struct gfal_scorer {
     uint32_t ct_mask = 0;
     int32_t *d_st_steps = nullptr, *d_st_len = nullptr;
     uint32_t *d_st_pass = nullptr, *d_st_g1 = nullptr;
+    // per stored path: a bitmap over the inverted list of its first node -- the entries
+    // the exact DP accepted -- and whether it is valid (paths kept by a full evaluation
+    // have none); the list position of every worklist entry, as pushed and sorted
+    uint32_t *d_st_bits = nullptr;
+    int32_t *d_st_bitsok = nullptr;
+    uint32_t bits_words = 0;
+    uint32_t *d_wl_pos = nullptr, *d_wl_pos_sorted = nullptr;
     int64_t st_cap = 0;
     int32_t *d_child_in = nullptr;     // [parent | step | slot] of a children batch, or the slots of a stored one
     int32_t *d_child_tmp = nullptr;    // root | depth | dpass | dg1   (or the G1 snapshot)
@@ -3656,7 +3739,8 @@ void free_scorer(gfal_scorer *s)
                     s->d_rows,       s->d_images,    s->d_path_off,   s->d_path_steps,
                     s->d_counts,     s->d_inv_off,   s->d_inv_ent,    s->d_ct_key,
                     s->d_ct_hash,    s->d_ct_mult,   s->d_st_steps,   s->d_st_len,
-                    s->d_st_pass,    s->d_st_g1,     s->d_child_in,   s->d_child_tmp};
+                    s->d_st_pass,    s->d_st_g1,     s->d_child_in,   s->d_child_tmp,
+                    s->d_st_bits,    s->d_st_bitsok, s->d_wl_pos,     s->d_wl_pos_sorted};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (s->graph_exec) (void)hipGraphExecDestroy(s->graph_exec);
@@ -3745,9 +3829,9 @@ int gfal_scorer_create_ex(const int32_t *aln_off, const int32_t *aln_steps,
 static const void *scan2_kernel(bool w, bool nm8, int grp)
 {
     typedef void (*kern_t)(Scan2Args);
-#define GFAL_ROW(W_, N_) {k_scan2<W_, N_, 0>, k_scan2<W_, N_, 1>, k_scan2<W_, N_, 2>, k_scan2<W_, N_, 3>, k_scan2<W_, N_, 4>}
-    static const kern_t table[2][2][SCAN2_GROUPS] = {{GFAL_ROW(false, false), GFAL_ROW(false, true)},
-                                                     {GFAL_ROW(true, false), GFAL_ROW(true, true)}};
+#define GFAL_ROW(W_, N_) {k_scan2<W_, N_, 0>, k_scan2<W_, N_, 1>, k_scan2<W_, N_, 2>, k_scan2<W_, N_, 3>, k_scan2<W_, N_, 4>, k_scan2<W_, N_, 5>}
+    static const kern_t table[2][2][SCAN2_GROUPS + 1] = {{GFAL_ROW(false, false), GFAL_ROW(false, true)},
+                                                         {GFAL_ROW(true, false), GFAL_ROW(true, true)}};
 #undef GFAL_ROW
     return reinterpret_cast<const void *>(table[w ? 1 : 0][nm8 ? 1 : 0][grp]);
 }
@@ -4325,7 +4409,7 @@ static int create_impl(const int32_t *aln_off, const int32_t *aln_steps, int64_t
                                    LDS_BUDGET));
     for (int w = 0; w < 2; ++w)
         for (int nm8 = 0; nm8 < 2; ++nm8)
-            for (int grp = 0; grp < SCAN2_GROUPS; ++grp)
+            for (int grp = 0; grp <= SCAN2_GROUPS; ++grp)
                 CREATE_TRY(hipFuncSetAttribute(scan2_kernel(w != 0, nm8 != 0, grp),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET));
     CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_prep),
@@ -4449,6 +4533,13 @@ static int grow_worklist(gfal_scorer *s, unsigned long long need)
     s->d_worklist = a;
     s->d_worklist_sorted = b;
     s->wl_capacity = (uint32_t)want;
+    if (s->d_wl_pos) {          // search mode keeps a list position beside every entry
+        (void)hipFree(s->d_wl_pos);
+        (void)hipFree(s->d_wl_pos_sorted);
+        s->d_wl_pos = s->d_wl_pos_sorted = nullptr;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_wl_pos), (size_t)want * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_wl_pos_sorted), (size_t)want * sizeof(uint32_t)));
+    }
     return GFAL_OK;
 }
 
@@ -4565,6 +4656,7 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
     uint32_t *const d_user_counts = d_counts;
     d_counts = s->d_counts_slot;
     const bool children = cx && cx->mode == 2;
+    const bool inherit = children && s->bits_words > 0;      // DP results remembered per stored path
     const int32_t *const d_order = children ? nullptr : s->d_order;      // (children: slot = index)
     if (children) {
         // (k_child_len cleared the status words)
@@ -4624,6 +4716,8 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
             c.max_aln_len = s->max_aln_len;
             c.dpass = cx->batch.dpass;
             c.dg1 = cx->batch.dg1;
+            c.b = cx->batch;
+            c.wl_pos = inherit ? s->d_wl_pos : nullptr;
             c.counts = d_counts;
             c.worklist = s->d_worklist;
             c.wl_count = wl_count;
@@ -4632,7 +4726,8 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
             c.status = s->d_status;
             int chunks = std::max(1, std::min(32, 8 * s->n_cus / (int)n_paths));
             if (const char *env = getenv("GFAL_CHILD_CHUNKS")) chunks = std::max(1, atoi(env));
-            const size_t lds_c = img_bytes + (size_t)L.nm * sizeof(uint16_t);
+            const size_t lds_c = img_bytes + (size_t)L.nm * sizeof(uint16_t) +
+                                 (size_t)((L.v2 + 31) / 32) * sizeof(uint32_t);
             if (lds_c > (size_t)LDS_MAX - CHILD_STATIC_LDS) {
                 set_err("%d local nodes exceed the LDS budget of the children kernel", s->n_local);
                 return GFAL_E_RANGE;
@@ -4693,15 +4788,17 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
                             (unsigned long long)std::max<int64_t>(items2, 1);
             a2.chunk_inv_min = (1ull << 24) / (unsigned long long)min_items;
             // one launch per run of segments of one length group (the lengths ascend: as
-            // many runs as groups that occur), side by side: the first on the caller's stream, the others on
-            // the side streams the DP kernels use later
+            // many runs as groups that occur), side by side: the first on the caller's
+            // stream, the others on the side streams the DP kernels use later
             int n_launch = 0;
             int &joined = scan_forks;
+            bool split = n_paths >= 4096;       // (see scan2_group)
+            if (const char *env = getenv("GFAL_SCAN2_SPLIT")) split = atoi(env) != 0;
             for (int s0 = 0; s0 < n_segs2;) {
-                const int grp = scan2_group((int)s->segs[(size_t)s0].m);
+                const int grp = split ? scan2_group((int)s->segs[(size_t)s0].m) : SCAN2_GROUPS;
                 int ns = 1;
                 while (s0 + ns < n_segs2 && ns < MAX_SEGS &&
-                       scan2_group((int)s->segs[(size_t)(s0 + ns)].m) == grp)
+                       (!split || scan2_group((int)s->segs[(size_t)(s0 + ns)].m) == grp))
                     ++ns;
                 a2.segs = s->d_segs + s0;
                 a2.n_segs = ns;
@@ -4712,7 +4809,10 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
                 }
                 const unsigned grid2 = (unsigned)a2.n_tiles * y_total;
                 hipStream_t on = st;
-                static const bool serial = getenv("GFAL_SCAN2_SERIAL") != nullptr;      // (measurements)
+                // (10 000-path batches at config 3, its 1/8 shard and config 5: within 1-2 %
+                // of one launch after the other, GFAL_SCAN2_SERIAL=1; a 128-path batch, whose
+                // launches are mostly prologue: 0.26 against 0.35 ms)
+                static const bool serial = getenv("GFAL_SCAN2_SERIAL") != nullptr;
                 if (n_launch > 0 && !serial) {
                     const int side = (n_launch - 1) % 3;
                     if (n_launch == 1) HIP_TRY(hipEventRecord(s->dp_fork, st));
@@ -4802,7 +4902,8 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
                            d_cursor, d_class_lo + 8, (int)n_paths);
         hipLaunchKernelGGL(k_wl_scatter, dim3(256), dim3(256), 0, st, a.items,
                            s->d_worklist, a.wl_count, s->wl_capacity, d_offsets,
-                           d_cursor, (uint32_t)n_paths, s->d_worklist_sorted, d_class_lo + 8, d_class_lo);
+                           d_cursor, (uint32_t)n_paths, s->d_worklist_sorted, d_class_lo + 8, d_class_lo,
+                           inherit ? s->d_wl_pos : nullptr, s->d_wl_pos_sorted);
         DpArgs d;
         d.items = a.items;
         d.images = s->d_images;
@@ -4815,6 +4916,10 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
         d.sys_limit = s->dp_sys_limit;
         d.row_scratch = s->d_rows;
         d.counts = d_counts;
+        d.sorted_pos = inherit ? s->d_wl_pos_sorted : nullptr;
+        d.bits = inherit ? s->d_st_bits : nullptr;
+        d.bits_words = s->bits_words;
+        d.q_slot = inherit ? cx->batch.slot : nullptr;
         // fork: classes 8 / 16 / 32+ on side streams, class 4 on the caller's
         HIP_TRY(hipEventRecord(s->dp_fork, st));
         int forked = 0;
@@ -4867,7 +4972,7 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
     if (cx && cx->mode == 1)
         hipLaunchKernelGGL(k_store_paths, dim3((unsigned)n_paths), dim3(256), 0, st, d_path_off, d_path_steps,
                            s->d_order, (int)n_paths, d_counts, cx->d_g1_tmp, cx->d_slots, s->d_st_steps,
-                           s->d_st_len, s->d_st_pass, s->d_st_g1, s->st_cap, s->d_status);
+                           s->d_st_len, s->d_st_pass, s->d_st_g1, s->d_st_bitsok, s->st_cap, s->d_status);
     if (children)
         hipLaunchKernelGGL(k_child_resolve, dim3(p_blocks), dim3(256), 0, st, cx->batch, (int)n_paths,
                            s->n_empty, d_counts, d_user_counts, s->d_status, status_copy);
@@ -5025,6 +5130,25 @@ static int build_child_index(gfal_scorer *s)
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipStreamSynchronize(st));
+    {
+        // the longest inverted list of a node bounds the per-path bitmaps (a list of more
+        // than 4 M alignments -- e.g. the one node that stands for everything outside the
+        // universe, which no path can start on -- is not remembered: its paths recompute)
+        std::vector<uint32_t> off((size_t)n_loc + 1);
+        HIP_TRY(hipMemcpy(off.data(), s->d_inv_off, off.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        uint32_t longest = 0;
+        for (int v = 0; v + N_CLASSES <= n_loc; v += N_CLASSES) {
+            const uint32_t len = off[(size_t)v + N_CLASSES] - off[(size_t)v];
+            if (len <= (4u << 20)) longest = std::max(longest, len);
+        }
+        s->bits_words = (longest + 31u) / 32u;
+        if (getenv("GFAL_NO_INHERIT")) s->bits_words = 0;
+        if (s->bits_words) {
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_wl_pos), (size_t)s->wl_capacity * sizeof(uint32_t)));
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_wl_pos_sorted),
+                              (size_t)s->wl_capacity * sizeof(uint32_t)));
+        }
+    }
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_child<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX - CHILD_STATIC_LDS));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_child<true>),
@@ -5053,6 +5177,28 @@ static int store_reserve(gfal_scorer *s, int64_t cap)
         return GFAL_E_NOMEM;
     }
     HIP_TRY(hipMemset(len, 0, n * sizeof(int32_t)));
+    if (s->bits_words) {
+        uint32_t *bits = nullptr;
+        int32_t *ok = nullptr;
+        if (hipMalloc(reinterpret_cast<void **>(&bits), n * s->bits_words * sizeof(uint32_t)) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void **>(&ok), n * sizeof(int32_t)) != hipSuccess) {
+            for (void *b : {(void *)steps, (void *)len, (void *)pass, (void *)g1, (void *)bits, (void *)ok})
+                if (b) (void)hipFree(b);
+            (void)hipGetLastError();
+            set_err("path store: cannot allocate %lld slots", (long long)cap);
+            return GFAL_E_NOMEM;
+        }
+        HIP_TRY(hipMemset(ok, 0, n * sizeof(int32_t)));
+        if (s->st_cap > 0) {
+            const size_t o = (size_t)s->st_cap;
+            HIP_TRY(hipMemcpy(bits, s->d_st_bits, o * s->bits_words * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+            HIP_TRY(hipMemcpy(ok, s->d_st_bitsok, o * sizeof(int32_t), hipMemcpyDeviceToDevice));
+            (void)hipFree(s->d_st_bits);
+            (void)hipFree(s->d_st_bitsok);
+        }
+        s->d_st_bits = bits;
+        s->d_st_bitsok = ok;
+    }
     if (s->st_cap > 0) {
         const size_t o = (size_t)s->st_cap;
         HIP_TRY(hipMemcpy(steps, s->d_st_steps, o * STORE_STRIDE * sizeof(int32_t), hipMemcpyDeviceToDevice));
@@ -5122,6 +5268,9 @@ static int children_stage(gfal_scorer *s, const int32_t *parent, const int32_t *
     b.depth = s->d_child_tmp + n;
     b.dpass = reinterpret_cast<uint32_t *>(s->d_child_tmp + 2 * (size_t)n);
     b.dg1 = reinterpret_cast<uint32_t *>(s->d_child_tmp + 3 * (size_t)n);
+    b.st_bits = s->d_st_bits;
+    b.st_bitsok = s->d_st_bitsok;
+    b.bits_words = s->bits_words;
     hipLaunchKernelGGL(k_child_len, dim3(1), dim3(1024), 0, st, b, (int)max_len, (int)s->max_aln_len,
                        s->d_path_off, s->d_status);
     hipLaunchKernelGGL(k_child_copy, dim3((unsigned)n), dim3(256), 0, st, b, s->d_path_off,

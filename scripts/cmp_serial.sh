@@ -1,11 +1,13 @@
 #!/bin/bash
-# GPU box: the bench step with the k_scan2 launches of a call side by side (default)
-# and one after the other on the caller's stream (GFAL_SCAN2_SERIAL=1)
+# GPU box: the k_scan2 launches of a call side by side on the side streams (default) and
+# one after the other on the caller's stream (GFAL_SCAN2_SERIAL=1): the bench step and
+# search-sized blocking calls
 cd "$GRAFT_REPO_ROOT" || exit 1
-for v in "" 1; do
-  if [ -n "$v" ]; then export GFAL_SCAN2_SERIAL=1; fi
+for v in parallel serial; do
+  if [ $v = serial ]; then export GFAL_SCAN2_SERIAL=1; fi
   python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-search-mode 2>/dev/null | python3 -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1]); r = d['roofline']
-print('serial' if '$v' else 'side by side', 'ms/step %.3f scan %.3f dp %.3f' % (d['ms_per_step'], r['kernel_ms'], r['dp_kernel_ms']))"
+print('$v', 'ms/step %.3f scan %.3f dp %.3f' % (d['ms_per_step'], r['kernel_ms'], r['dp_kernel_ms']))"
+  python3 scripts/small_batch_probe.py config3 128,512,2048 | sed "s/^/$v /"
 done

@@ -116,3 +116,23 @@ def dp_candidates(A, idx):
         if (has_overhang(A, B) or has_overhang(A, rc(B))) and not found(A, B):
             out.append(k)
     return out
+
+
+def dp_status(A, B):
+    """None: B is no DP candidate of A; else whether the DP accepts it (what G2 counts)."""
+    nodes = {a >> 1 for a in A}
+    if len(B) == 0 or len(B) > len(A) or any((b >> 1) not in nodes for b in B) or found(A, B):
+        return None
+    fw, rv = has_overhang(A, B), has_overhang(A, rc(B))
+    if not (fw or rv):
+        return None
+    return (fw and traceback_score(A, B) == 0) or (rv and traceback_score(A, rc(B)) == 0)
+
+
+def inherits(A2, d, B):
+    """k_child's test: may B's DP status be taken from the ancestor d steps up the path A2?
+    Yes if none of the last len(B) + d steps of A2 is on a node of B: the d new rows and the
+    len(B) rows before them only subtract, so the table was in its steady state at the
+    ancestor and stays there (DESIGN.md, row skipping), and no new node or window concerns B."""
+    nb = {b >> 1 for b in B}
+    return all((a >> 1) not in nb for a in A2[max(0, len(A2) - (len(B) + d)):])

@@ -184,7 +184,7 @@ def test_long_paths_many_candidates_against_the_full_scorer(gpu):
     alns = walk_alignments(rnd, walk, n_nodes, 60000, 24, mutate=0.1, zero=0.001)
     aoff, ast = csr(alns)
     with Scorer(aoff, ast, n_nodes) as sc, Group([sc]) as g:
-        tree = Tree(g, 1024)
+        tree = Tree(g, 2048)
         cuts = [40, 77, 150, 199, 229, 310, 399]
         roots = [walk[:c] for c in cuts]
         slots, res = tree.store(roots)
@@ -201,6 +201,22 @@ def test_long_paths_many_candidates_against_the_full_scorer(gpu):
         slot, full, res = tree.children(batch)
         poff, pst = csr(full)
         assert_same(res, g.evaluate_paths(poff, pst, True), "children vs full")
+        # the next generations: parents that were children themselves carry the DP verdicts
+        # of the alignments on their first node, and their children inherit them unless the
+        # path's tail comes back to such an alignment (steps near the start do: recomputed)
+        gen, gen_full = slot, full
+        for g_no in range(3):
+            batch2, picks = [], rnd.sample(range(len(gen_full) - 6), 60)
+            for k in picks:
+                nxt = walk[len(gen_full[k])] if len(gen_full[k]) < len(walk) else walk[3]
+                for st in (nxt, walk[rnd.randrange(0, 6)] ^ rnd.randrange(2), (rnd.randrange(n_nodes) << 1) | 1):
+                    batch2.append((("slot", gen[k]), st))
+            for k in range(5):
+                batch2.append((("batch", 3 * k), walk[rnd.randrange(0, 40)]))
+                batch2.append((("batch", len(batch2) - 1), walk[rnd.randrange(0, 40)] ^ 1))
+            gen, gen_full, res2 = tree.children(batch2)
+            poff2, pst2 = csr(gen_full)
+            assert_same(res2, g.evaluate_paths(poff2, pst2, True), "generation %d vs full" % (g_no + 2))
         sample = rnd.sample(range(len(full)), 12)
         exp = expect(alns[:8000], [full[k] for k in sample])
         with Scorer(aoff[:8001], ast[:aoff[8000]], n_nodes) as small, Group([small]) as g2:

@@ -55,3 +55,27 @@ def test_longest_old_window():
     # appending 2- after ...2+ : rc(2+ 2-) = (2+ 2-) occurs only in the child itself
     assert im.longest_old_window(A, 5) == 1
     assert im.longest_old_window(A, 8) == 0
+
+
+def test_dp_status_is_inherited_when_the_tail_avoids_the_alignment():
+    rnd = random.Random(5)
+    inherited = changed = 0
+    for it in range(40):
+        n_nodes = rnd.choice([3, 5, 8, 14])
+        max_m = rnd.choice([2, 3, 5])
+        walk, alns = _case(rnd, n_nodes, max_m, 80, 40)
+        idx = im.Index(alns)
+        A = walk[:idx.max_m + rnd.randrange(4)]
+        for depth_run in range(6):
+            R = list(A)
+            for d in range(1, 4):          # chains of up to three steps above a stored ancestor
+                A = A + [(rnd.randrange(n_nodes + 2) << 1) | rnd.randrange(2)]
+                for B in alns:
+                    if len(B) == 0:
+                        continue
+                    if im.inherits(A, d, B):
+                        assert im.dp_status(A, B) == im.dp_status(R, B), (R, A, B)
+                        inherited += 1
+                    elif im.dp_status(A, B) != im.dp_status(R, B):
+                        changed += 1
+    assert inherited > 2000 and changed > 0      # (the test is not vacuous either way)
