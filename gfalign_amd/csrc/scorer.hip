@@ -530,6 +530,9 @@ __device__ __forceinline__ void push_item_pairs(unsigned long long *worklist,
 {
     const uint32_t any = fw | rc;
     if (!WAVE_ANY(any != 0u)) return;
+#if defined(GFAL_ABLATE) && GFAL_ABLATE == 8      // timing probe: what do the appends cost?
+    return;
+#endif
     const uint32_t cls = (uint32_t)length_class(M);
     uint32_t total = 0;
     for (int p = 0; p < tile_paths; ++p) {
