@@ -3062,12 +3062,17 @@ struct ChildBatch {
 // lengths and offsets of the batch's paths (one workgroup)
 __global__ __launch_bounds__(1024) void k_child_len(ChildBatch b, int max_len, int min_parent_len,
                                                     int32_t *__restrict__ path_off,
-                                                    uint32_t *__restrict__ status)
+                                                    uint32_t *__restrict__ status,
+                                                    const int32_t *__restrict__ host_in, int32_t *__restrict__ dev_in)
 {
     __shared__ uint32_t part[1024];
     // a children batch is not sorted by length (k_child's cost does not follow it): this
     // kernel also does what k_len_sort_block does besides sorting, clearing the status words
     if (threadIdx.x < 8) status[threadIdx.x] = 0;
+    // the batch itself ([parent | step | slot], a few KB) is read straight from the
+    // caller's pinned staging buffer: one copy operation less in front of every call
+    if (host_in)
+        for (int i = threadIdx.x; i < 3 * b.n; i += 1024) dev_in[i] = host_in[i];
     __syncthreads();
     const int tid = threadIdx.x, per = (b.n + 1023) / 1024;
     const int lo = min(tid * per, b.n), hi = min(lo + per, b.n);
@@ -3205,8 +3210,8 @@ __device__ __forceinline__ uint32_t ct_lookup(const ChildArgs &a, uint32_t h, in
 // time: its first step in a register, the others (up to 33 steps) as pair dwords in
 // the lane's own LDS column, so the divergent per-lane loops below read LDS, not HBM.
 constexpr int CHILD_WAVES = CHILD_THREADS / WAVE;
-constexpr int CHILD_STAGE_PAIRS = 16;
-constexpr int CHILD_WL_BUF = 1024;             // worklist entries a workgroup gathers before it appends them
+constexpr int CHILD_STAGE_PAIRS = 8;
+constexpr int CHILD_WL_BUF = 512;              // worklist entries a workgroup gathers before it appends them
 constexpr int CHILD_STATIC_LDS = CHILD_WAVES * CHILD_STAGE_PAIRS * WAVE * 4 + CHILD_WL_BUF * 12 + 256;
 
 template <bool W>
@@ -3671,6 +3676,7 @@ struct gfal_scorer {
     int32_t *d_child_tmp = nullptr;    // root | depth | dpass | dg1   (or the G1 snapshot)
     size_t child_in_cap = 0, child_tmp_cap = 0;
     int64_t n_children_calls = 0;
+    bool out_on_host = false;          // the last call's kernels wrote the counters into h_out themselves
 
     int64_t n_score_calls = 0, n_device_passes = 0, n_overflow_reruns = 0;
     // status words of the last blocking call (they came back with its counters):
@@ -5225,7 +5231,7 @@ static int store_reserve(gfal_scorer *s, int64_t cap)
 // the device, then the usual pipeline with k_child in place of the scans.  Counters
 // are left in s->d_counts like score_stage does.
 static int children_stage(gfal_scorer *s, const int32_t *parent, const int32_t *step, const int32_t *slot,
-                          int32_t n, int32_t max_len)
+                          int32_t n, int32_t max_len, bool direct_out)
 {
     int rc;
     if ((rc = build_child_index(s))) return rc;
@@ -5254,7 +5260,20 @@ static int children_stage(gfal_scorer *s, const int32_t *parent, const int32_t *
         HIP_TRY(hipEventRecord(s->order_ev, s->last_stream));
         HIP_TRY(hipStreamWaitEvent(st, s->order_ev, 0));
     }
-    HIP_TRY(hipMemcpyAsync(s->d_child_in, s->h_in, n_in * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    // pinned host memory is device-visible: the first kernel reads the batch from it and,
+    // when this shard's counters are the result (no sum over shards), the last one writes
+    // them into the pinned output -- no copy operations around a children call
+    int32_t *h_in_dev = nullptr;
+    uint32_t *h_out_dev = nullptr;
+    if (getenv("GFAL_CHILD_COPIES") == nullptr) {
+        if (hipHostGetDevicePointer(reinterpret_cast<void **>(&h_in_dev), s->h_in, 0) != hipSuccess) h_in_dev = nullptr;
+        if (!direct_out ||
+            hipHostGetDevicePointer(reinterpret_cast<void **>(&h_out_dev), s->h_out, 0) != hipSuccess)
+            h_out_dev = nullptr;
+        (void)hipGetLastError();
+    }
+    if (!h_in_dev)
+        HIP_TRY(hipMemcpyAsync(s->d_child_in, s->h_in, n_in * sizeof(int32_t), hipMemcpyHostToDevice, st));
     ExtraCtx cx;
     cx.mode = 2;
     ChildBatch &b = cx.batch;
@@ -5275,15 +5294,17 @@ static int children_stage(gfal_scorer *s, const int32_t *parent, const int32_t *
     b.st_bitsok = s->d_st_bitsok;
     b.bits_words = s->bits_words;
     hipLaunchKernelGGL(k_child_len, dim3(1), dim3(1024), 0, st, b, (int)max_len, (int)s->max_aln_len,
-                       s->d_path_off, s->d_status);
+                       s->d_path_off, s->d_status, (const int32_t *)h_in_dev, s->d_child_in);
     hipLaunchKernelGGL(k_child_copy, dim3((unsigned)n), dim3(256), 0, st, b, s->d_path_off,
                        s->d_path_off + n + 1);
     HIP_TRY(hipGetLastError());
     ++s->n_children_calls;
+    uint32_t *const out = h_out_dev ? h_out_dev : s->d_counts;
     rc = score_device_impl(s, s->d_path_off, s->d_path_off + n + 1, n, (int64_t)n * max_len, max_len, 1,
-                           s->d_counts, st, s->d_counts + (size_t)3 * n, &cx);
+                           out, st, out + (size_t)3 * n, &cx);
     s->last_stream = st;
     s->have_last = true;
+    s->out_on_host = h_out_dev != nullptr;
     return rc;
 }
 
@@ -5524,8 +5545,9 @@ static int group_enqueue(gfal_group *g, const int32_t *path_off, const int32_t *
     for (size_t d = 0; d < D; ++d) {
         gfal_scorer *s = g->shards[d];
         HIP_TRY(hipSetDevice(s->device));
+        s->out_on_host = false;
         const int rc = g->pend_kind == 2
-                           ? children_stage(s, path_off, path_steps, slots, P, g->pend_max_len)
+                           ? children_stage(s, path_off, path_steps, slots, P, g->pend_max_len, D == 1 && g->comms.empty())
                            : score_stage(s, path_off, path_steps, P, g->pend_max_len, g->pend_filter,
                                          g->pend_kind == 1 ? slots : nullptr);
         if (rc) return rc;
@@ -5553,7 +5575,9 @@ static int group_enqueue(gfal_group *g, const int32_t *path_off, const int32_t *
         HIP_TRY(hipSetDevice(s->device));
         // (k_unpermute put the status words behind the counters BEFORE the all-reduce
         // touched the first 3P words: one copy takes both)
-        if (g->comms.empty() || d == 0)
+        if (s->out_on_host) {
+            // (a children batch on the group's only shard: already there)
+        } else if (g->comms.empty() || d == 0)
             HIP_TRY(hipMemcpyAsync(s->h_out, s->d_counts, (n_cnt + 4) * sizeof(uint32_t), hipMemcpyDeviceToHost,
                                    s->stream));
         else
