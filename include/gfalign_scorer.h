@@ -212,8 +212,11 @@ int  gfal_group_score_end(gfal_group *g, uint32_t *bad, uint32_t *good, uint32_t
  * the sense of SURVEY.md 8(d): bench.py reports it next to the headline figure.
  *
  *   gfal_group_store_reserve         room for n_slots scored paths on every shard
- *                                    (4 KB each; grows, keeps what is there); the
- *                                    first call also builds the index on the devices
+ *                                    (4 KB each, plus one bit per alignment of the
+ *                                    longest inverted list: the exact DP's verdicts,
+ *                                    which a child inherits where its tail avoids the
+ *                                    alignment; grows, keeps what is there); the first
+ *                                    call also builds the index on the devices
  *   gfal_group_score_store_begin     gfal_group_score_begin with filter = 1 that also
  *                                    keeps path p in slot slots[p] (-1: not kept)
  *   gfal_group_score_children_begin  child i = parent[i] + step[i]; parent[i] >= 0 is
