@@ -2679,33 +2679,45 @@ __device__ __forceinline__ void sys_step(int s, int j, int n, uint32_t b, int up
     l_dp = active ? v : l_dp;
 }
 
+// LDS of one workgroup of the wavefront DP
 template <int MC>
-__global__ __launch_bounds__(DP_THREADS) void k_dp_sys(DpArgs a)
+struct DpSysLds {
+    static constexpr int ENTRIES = MC == 64 ? 1 : WAVE / MC / 2;
+    static constexpr int ROWLEN = GFAL_MAX_STEPS + 2 * MC + 8;      // (reads of idle lanes stay inside)
+    static constexpr int BYTES = ENTRIES * (2 * ROWLEN * 2 + 2 * (ROW_WORDS + 2) * 4);
+};
+
+// block `block` of `n_blocks` of the wavefront DP over its length class; always = the
+// class is this function's whatever its size (k_dp_small)
+template <int MC>
+__device__ __forceinline__ void dp_sys_body(const DpArgs &a, uint32_t block, uint32_t n_blocks,
+                                            unsigned char *smem, bool always)
 {
     static_assert(MC == 4 || MC == 8 || MC == 16 || MC == 64, "group inside a DPP row, or the wave");
-    constexpr int G = WAVE / MC;                          // lane groups (fills) per wave
     // MC < 64: an entry takes two neighbouring groups, one per orientation;
     // MC = 64: one entry per wave, the orientations one after the other
-    constexpr int ENTRIES = MC == 64 ? 1 : G / 2;
-    constexpr int PAD = MC;                               // reads of idle lanes stay inside
+    constexpr int ENTRIES = DpSysLds<MC>::ENTRIES;
+    constexpr int ROWLEN = DpSysLds<MC>::ROWLEN;
+    constexpr int PAD = MC;
     // per entry (its two orientation groups write the same values)
-    __shared__ uint16_t apath[ENTRIES][GFAL_MAX_STEPS + 2 * PAD + 8];   // the entries' paths
-    __shared__ uint16_t alist[ENTRIES][GFAL_MAX_STEPS + 2 * PAD + 8];   // their steps at the rows to compute
-    __shared__ uint32_t rowmark[ENTRIES][ROW_WORDS + 2];  // rows whose node occurs in B
-    __shared__ uint32_t rowsel[ENTRIES][ROW_WORDS + 2];   // rows to compute
+    uint16_t (*apath)[ROWLEN] = reinterpret_cast<uint16_t (*)[ROWLEN]>(smem);          // the entries' paths
+    uint16_t (*alist)[ROWLEN] = apath + ENTRIES;                  // their steps at the rows to compute
+    uint32_t (*rowmark)[ROW_WORDS + 2] =
+        reinterpret_cast<uint32_t (*)[ROW_WORDS + 2]>(alist + ENTRIES);                // rows whose node occurs in B
+    uint32_t (*rowsel)[ROW_WORDS + 2] = rowmark + ENTRIES;        // rows to compute
     if (*a.wl_count > a.wl_capacity) return;              // overflow: see k_wl_scatter
     const uint32_t total = (uint32_t)*a.wl_count;
     // MC = 4, 8, 16: classes 0, 1, 2; MC = 64: class 3 and the entries of the last
     // class that fit (k_dp_long skips those on a short list)
     constexpr int CLS = MC == 4 ? 0 : MC == 8 ? 1 : MC == 16 ? 2 : 3;
-    if (!wavefront_class(a, total, CLS)) return;          // many entries: k_dp_regs / k_dp_long
+    if (!always && !wavefront_class(a, total, CLS)) return;       // many entries: k_dp_regs / k_dp_long
     const uint32_t lo = min(a.class_lo[CLS], total);
     const uint32_t hi = MC == 64 ? total : min(a.class_lo[CLS + 1], total);
     const int lane = threadIdx.x;
     const int c = lane % MC, g = lane / MC;
     const int en = MC == 64 ? 0 : g / 2;                  // my entry of the wave
     const int j = c + 1;
-    for (uint32_t w0 = lo + blockIdx.x * ENTRIES; w0 < hi; w0 += gridDim.x * ENTRIES) {
+    for (uint32_t w0 = lo + block * ENTRIES; w0 < hi; w0 += n_blocks * ENTRIES) {
         const uint32_t w = w0 + en;
         const DpEntry e = load_entry(a, w, w < hi);
         const bool live = w < hi && e.m <= MC;
@@ -2847,6 +2859,32 @@ __global__ __launch_bounds__(DP_THREADS) void k_dp_sys(DpArgs a)
         const lanemask mine = (gm >> (lane / SPAN * SPAN)) & (SPAN == 64 ? ~0ull : ((1ull << SPAN) - 1ull));
         // one result per entry, carried by the first lane of its span
         add_results_by_path(a, e.p, live && lane % SPAN == 0, mine != 0, lane, e.w, e.pos);
+    }
+}
+
+template <int MC>
+__global__ __launch_bounds__(DP_THREADS) void k_dp_sys(DpArgs a)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char smem[DpSysLds<MC>::BYTES];
+    dp_sys_body<MC>(a, blockIdx.x, gridDim.x, smem, false);
+}
+
+// The search's batches leave the exact DP a few hundred to a few thousand pairs in all:
+// one launch for every length class (grid.y) instead of a fork over four streams with a
+// wavefront and a register kernel each, most of which find an empty or short list.
+// The host picks it when the previous call's list was short (and no alignment is
+// longer than a wave); a longer list than expected is still decided exactly, only
+// more slowly than the register kernels would.
+__global__ __launch_bounds__(DP_THREADS) void k_dp_small(DpArgs a)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char smem[DpSysLds<4>::BYTES];      // the largest of the four
+    static_assert(DpSysLds<4>::BYTES >= DpSysLds<8>::BYTES && DpSysLds<4>::BYTES >= DpSysLds<16>::BYTES &&
+                      DpSysLds<4>::BYTES >= DpSysLds<64>::BYTES, "LDS of k_dp_small");
+    switch (blockIdx.y) {
+    case 0: dp_sys_body<4>(a, blockIdx.x, gridDim.x, smem, true); break;
+    case 1: dp_sys_body<8>(a, blockIdx.x, gridDim.x, smem, true); break;
+    case 2: dp_sys_body<16>(a, blockIdx.x, gridDim.x, smem, true); break;
+    default: dp_sys_body<64>(a, blockIdx.x, gridDim.x, smem, true); break;
     }
 }
 
@@ -4608,6 +4646,10 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
         HIP_TRY(hipStreamWaitEvent(st, s->order_ev, 0));
     }
     ++s->n_device_passes;
+    // the previous blocking call's exact-DP list, if its status words came back with it
+    const long long prev_dp_pairs =
+        s->status_cached ? (long long)((unsigned long long)s->cached_status[2] | ((unsigned long long)s->cached_status[3] << 32))
+                         : -1;
     s->status_cached = false;
 
     const ImageLayout L = make_layout(s->n_local, max_path_len);
@@ -4929,8 +4971,15 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
         d.bits = inherit ? s->d_st_bits : nullptr;
         d.bits_words = s->bits_words;
         d.q_slot = inherit ? cx->batch.slot : nullptr;
+        // a search's batches: a short list last time (and no alignment longer than a wave)
+        // -> one launch for all classes
+        static const bool dp_small_off = getenv("GFAL_DP_SMALL") != nullptr && atoi(getenv("GFAL_DP_SMALL")) == 0;
+        const bool dp_small = children && !dp_small_off && prev_dp_pairs >= 0 && prev_dp_pairs <= 16384 &&
+                              s->max_aln_len <= 64;
+        if (dp_small)
+            hipLaunchKernelGGL(k_dp_small, dim3(512, 4), dim3(DP_THREADS), 0, st, d);
         // fork: classes 8 / 16 / 32+ on side streams, class 4 on the caller's
-        HIP_TRY(hipEventRecord(s->dp_fork, st));
+        if (!dp_small) HIP_TRY(hipEventRecord(s->dp_fork, st));
         int forked = 0;
         auto side = [&](int i) -> hipStream_t {
             (void)hipStreamWaitEvent(s->dp_stream[i], s->dp_fork, 0);
@@ -4939,6 +4988,7 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
         };
         // every kernel of both families is launched; the list length (known on
         // the device only) decides which family returns at once
+        if (!dp_small) {
         hipLaunchKernelGGL(k_dp_sys<4>, dim3(DP_SYS_BLOCKS), dim3(DP_THREADS), 0, st, d);
         hipLaunchKernelGGL((k_dp_regs<4, 0>), dim3(DP_REG_BLOCKS), dim3(DP_THREADS), 0, st, d);
         if (s->max_aln_len > 4) {
@@ -4964,6 +5014,7 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
                     hipLaunchKernelGGL(k_dp_long<false>, dim3(DP_BLOCKS), dim3(DP_THREADS), 0,
                                        s2, d);
             }
+        }
         }
         for (int i = 0; i < 3; ++i)        // join
             if (forked & (1 << i)) {
