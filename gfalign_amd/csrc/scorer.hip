@@ -189,6 +189,15 @@ struct Items {
 constexpr uint32_t NO_COMMON_NODE = 0xFFFFFFFFu;
 constexpr uint32_t COMMON_EITHER = 0x8000u;   // Items::common: every lane has the one node OR the other
 
+// A children batch (search mode, see k_child): the path of candidate p is the stored
+// path `root[p]` plus the steps of `depth[p]` candidates of the batch, p last; k_prep
+// reads it from there and keeps it in the candidate's own store slot.
+constexpr int STORE_STRIDE = GFAL_MAX_STEPS;     // int32 steps per store slot
+struct PrepChild {
+    const int32_t *root = nullptr, *depth = nullptr, *parent = nullptr, *step = nullptr, *slot = nullptr;
+    int32_t *st_steps = nullptr, *st_len = nullptr;
+};
+
 // --------------------------------------------------------------------------
 // k_prep: candidate path -> lookup image (+ counter initialisation)
 // --------------------------------------------------------------------------
@@ -200,7 +209,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(
     uint32_t n_empty, int filter, ImageLayout L,
     const int32_t *__restrict__ order, uint16_t *__restrict__ images,
     uint32_t *__restrict__ counts, uint32_t *__restrict__ status,
-    uint32_t *__restrict__ wl_hist, uint16_t *__restrict__ lids_out)
+    uint32_t *__restrict__ wl_hist, uint16_t *__restrict__ lids_out, PrepChild pc)
 {
     extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
     uint16_t *img = smem;
@@ -238,8 +247,24 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(
     }
 
     bool id_ok = true;
+    // (children batch: from the stored ancestor, the last `depth` steps from the batch)
+    const int c_root = pc.root ? pc.root[p] : 0;
+    const int c_l0 = pc.root ? n - pc.depth[p] : n;
+    const int c_slot = (pc.root && c_root >= 0) ? pc.slot[p] : -1;
     for (int i = lane; i < n; i += PREP_THREADS) {
-        int32_t s = path_steps[off + i];
+        int32_t s;
+        if (!pc.root) {
+            s = path_steps[off + i];
+        } else if (c_root < 0) {
+            s = 0;                                  // (rejected by k_child_len: a one-step dummy)
+        } else if (i < c_l0) {
+            s = pc.st_steps[(size_t)c_root * STORE_STRIDE + i];
+        } else {
+            int j = p;
+            for (int k = n - 1 - i; k > 0; --k) j = ~pc.parent[j];
+            s = pc.step[j];
+        }
+        if (c_slot >= 0) pc.st_steps[(size_t)c_slot * STORE_STRIDE + i] = s;
         bool other = (s & GFAL_STEP_OTHER) != 0;
         int32_t id = (s & ~GFAL_STEP_OTHER) >> 1;
         uint32_t neg = (uint32_t)s & 1u;
@@ -302,6 +327,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(
     if (lane == 0) {
         img[L.len_at()] = (uint16_t)n;
         img[L.len_at() + 1] = 0;
+        if (c_slot >= 0) pc.st_len[c_slot] = n;
     }
     __syncthreads();
 
@@ -2978,7 +3004,6 @@ __global__ void k_fill_i32(int32_t *p, long long n, int32_t v)
 // an earlier child of the same batch.
 // --------------------------------------------------------------------------
 namespace {
-constexpr int STORE_STRIDE = GFAL_MAX_STEPS;     // int32 steps per store slot
 constexpr int CHILD_MAX_DEPTH = 64;              // in-batch ancestors of one child
 constexpr int CHILD_THREADS = 256;
 constexpr uint32_t CT_EMPTY = 0xFFFFFFFFu;
@@ -3146,6 +3171,8 @@ __global__ __launch_bounds__(1024) void k_child_len(ChildBatch b, int max_len, i
         }
         b.root[i] = good ? r : -1;
         b.depth[i] = d;
+        b.dpass[i] = 0;
+        b.dg1[i] = 0;
         path_off[i + 1] = L;
         sum += (uint32_t)L;
     }
@@ -3162,42 +3189,6 @@ __global__ __launch_bounds__(1024) void k_child_len(ChildBatch b, int max_len, i
     for (int i = lo; i < hi; ++i) {
         run += (uint32_t)path_off[i + 1];
         path_off[i + 1] = (int32_t)run;
-    }
-}
-
-// the batch's paths, written out (and into their store slots): one workgroup per child
-__global__ __launch_bounds__(256) void k_child_copy(ChildBatch b, const int32_t *__restrict__ path_off,
-                                                    int32_t *__restrict__ path_steps)
-{
-    const int i = blockIdx.x, tid = threadIdx.x;
-    const int off = path_off[i], L = path_off[i + 1] - off;
-    const int r = b.root[i], d = b.depth[i];
-    const int slot = r >= 0 ? b.slot[i] : -1;
-    int32_t *keep = slot >= 0 ? b.st_steps + (size_t)slot * STORE_STRIDE : nullptr;
-    if (tid == 0) {
-        b.dpass[i] = 0;
-        b.dg1[i] = 0;
-    }
-    if (r < 0) {           // rejected by k_child_len: a one-step dummy
-        if (tid == 0) path_steps[off] = 0;
-        return;
-    }
-    const int l0 = L - d;
-    const int32_t *src = b.st_steps + (size_t)r * STORE_STRIDE;
-    for (int k = tid; k < l0; k += 256) {
-        const int32_t v = src[k];
-        path_steps[off + k] = v;
-        if (keep) keep[k] = v;
-    }
-    if (tid == 0) {
-        int j = i;
-        for (int k = d - 1; k >= 0; --k) {
-            const int32_t v = b.step[j];
-            path_steps[off + l0 + k] = v;
-            if (keep) keep[l0 + k] = v;
-            j = ~b.parent[j];
-        }
-        if (slot >= 0) b.st_len[slot] = L;
     }
 }
 
@@ -4722,11 +4713,21 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
         hipLaunchKernelGGL(k_len_scatter, dim3(p_blocks), dim3(256), 0, st, d_path_off,
                            (int)n_paths, s->d_len_bins, s->d_order);
     }
+    PrepChild pc;
+    if (children) {
+        pc.root = cx->batch.root;
+        pc.depth = cx->batch.depth;
+        pc.parent = cx->batch.parent;
+        pc.step = cx->batch.step;
+        pc.slot = cx->batch.slot;
+        pc.st_steps = cx->batch.st_steps;
+        pc.st_len = cx->batch.st_len;
+    }
     hipLaunchKernelGGL(k_prep, dim3((unsigned)n_paths), dim3(PREP_THREADS), prep_lds, st,
                        d_path_off, d_path_steps, (int)n_paths, total_steps,
                        (int)max_path_len, s->d_node_local, (int)s->n_nodes,
                        s->d_node_hist, (uint32_t)s->n_steps, s->n_empty, filter, L,
-                       d_order, s->d_images, d_counts, s->d_status, d_hist, s->d_lids);
+                       d_order, s->d_images, d_counts, s->d_status, d_hist, s->d_lids, pc);
     HIP_TRY(hipGetLastError());
     if (s->profiling) HIP_TRY(hipEventRecord(ev[1], st));
 
@@ -5291,7 +5292,7 @@ static int children_stage(gfal_scorer *s, const int32_t *parent, const int32_t *
         return GFAL_E_ARG;
     }
     const size_t n_in = (size_t)3 * n, n_out = (size_t)3 * n + 4;
-    const size_t n_paths_buf = (size_t)n + 1 + (size_t)n * (size_t)max_len;
+    const size_t n_paths_buf = (size_t)n + 1;      // offsets only: k_prep reads the paths from the store
     if (s->have_last && (n_in > s->child_in_cap || (size_t)4 * n > s->child_tmp_cap ||
                          n_paths_buf > s->path_off_cap || n_out > s->counts_cap))
         HIP_TRY(hipStreamSynchronize(s->last_stream));
@@ -5346,8 +5347,6 @@ static int children_stage(gfal_scorer *s, const int32_t *parent, const int32_t *
     b.bits_words = s->bits_words;
     hipLaunchKernelGGL(k_child_len, dim3(1), dim3(1024), 0, st, b, (int)max_len, (int)s->max_aln_len,
                        s->d_path_off, s->d_status, (const int32_t *)h_in_dev, s->d_child_in);
-    hipLaunchKernelGGL(k_child_copy, dim3((unsigned)n), dim3(256), 0, st, b, s->d_path_off,
-                       s->d_path_off + n + 1);
     HIP_TRY(hipGetLastError());
     ++s->n_children_calls;
     uint32_t *const out = h_out_dev ? h_out_dev : s->d_counts;
@@ -5859,7 +5858,8 @@ static int pair_scores_impl(gfal_scorer *s, const int32_t *path_steps, int32_t n
     hipLaunchKernelGGL(k_prep, dim3(1), dim3(PREP_THREADS), prep_lds, s->stream, s->d_path_off,
                        s->d_path_steps, 1, (int64_t)n, (int)n, s->d_node_local,
                        (int)s->n_nodes, s->d_node_hist, (uint32_t)s->n_steps,
-                       s->n_empty, 0, L, nullptr, s->d_images, s->d_counts, s->d_status, nullptr, nullptr);
+                       s->n_empty, 0, L, nullptr, s->d_images, s->d_counts, s->d_status, nullptr, nullptr,
+                       PrepChild());
     HIP_TRY(hipGetLastError());
 
     // device results are indexed like the caller's alignments (all shards)
