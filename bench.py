@@ -74,7 +74,7 @@ def search_mode(t, device):
             if p.returncode != 0:
                 return {"error": "gfalign search failed: " + p.stderr[-300:]}
             stdout[key] = p.stdout
-            m1 = re.search(r"search ([0-9.]+) s \(candidates ([0-9.]+) s, scoring ([0-9.]+) s\)", p.stderr)
+            m1 = re.search(r"search ([0-9.]+) s \(candidates ([0-9.]+) s, scoring ([0-9.]+) s", p.stderr)
             m2 = re.search(r"scored (\d+) candidate paths in (\d+) batches, (\d+) of them in full", p.stderr)
             if m1 and m2:
                 scored, nb = int(m2.group(1)), int(m2.group(2))

@@ -403,7 +403,7 @@ public:
         }
 
         auto first = std::make_unique<Node>();
-        first->path.push_back(GFAL_STEP_OTHER | (int32_t)(src_uid << 1));   // :130, orientation '0'
+        first->set_path({GFAL_STEP_OTHER | (int32_t)(src_uid << 1)});       // :130, orientation '0'
         first->uniques = 1;
         first->scored = true;           // (never scored: its key is 0 by definition, :132)
         queue_.emplace(Key{0, seq_++}, std::move(first));                   // :132
@@ -422,7 +422,7 @@ public:
                     queue_.emplace(Key{alt, seq_++}, std::move(c));
                 } else {                                                    // :170-184
                     ++path_counter;
-                    const bool ham = table.hamiltonian(c->path);
+                    const bool ham = table.hamiltonian(c->path());
                     bool print = false;
                     if (c->uniques >= opt_.min_nodes &&
                         (best_uniques < c->uniques ||
@@ -433,8 +433,8 @@ public:
                     }
                     if (opt_.return_all_paths || print)
                         out_ << path_counter << '\t' << c->bad << '\t' << c->good << '\t' << alt
-                             << '\t' << c->path.size() << '\t' << c->uniques << '\t'
-                             << (ham ? 'T' : 'F') << '\t' << path_string(c->path, g_)
+                             << '\t' << c->len << '\t' << c->uniques << '\t'
+                             << (ham ? 'T' : 'F') << '\t' << path_string(c->path(), g_)
                              << std::endl;
                 }
             }
@@ -461,7 +461,31 @@ private:
     // occurrences in path[1..] (every non-destination extension decrements it once,
     // :166-167; the source at path[0] was never an extension), see make_kids.
     struct Node {
-        std::vector<int32_t> path;      // packed steps, as the scorer takes them
+        // The path (packed steps, as the scorer takes them): written out once somebody
+        // needs all of it -- the entry is extended, printed, or scored in full -- and
+        // until then the parent's path (shared by its extensions) plus one step.  Most
+        // candidates are scored from their parents on the device and never popped.
+        std::shared_ptr<std::vector<int32_t>> full, base;
+        int32_t last = 0;
+        uint32_t len = 0;
+        void set_path(std::vector<int32_t> p)
+        {
+            len = (uint32_t)p.size();
+            last = p.back();
+            full = std::make_shared<std::vector<int32_t>>(std::move(p));
+            base.reset();
+        }
+        const std::vector<int32_t> &path()
+        {
+            if (!full) {
+                full = std::make_shared<std::vector<int32_t>>();
+                full->reserve(len);
+                full->assign(base->begin(), base->end());
+                full->push_back(last);
+                base.reset();
+            }
+            return *full;
+        }
         uint32_t uniques = 0, bad = 0, good = 0;
         bool at_destination = false;
         bool scored = false;            // bad / good are known (queue entries, finished batches)
@@ -486,11 +510,12 @@ private:
     void make_kids(Node &e) const
     {
         e.kids_made = true;
-        const int32_t last = e.path.back();
+        const std::vector<int32_t> &ep = e.path();
+        const int32_t last = ep.back();
         const bool fresh = (last & GFAL_STEP_OTHER) != 0;          // orientation still '0'
         const uint32_t last_id = (uint32_t)(last & ~GFAL_STEP_OTHER) >> 1;
         const char last_orient = (last & 1) ? '-' : '+';
-        const size_t n = e.path.size();
+        const size_t n = ep.size();
         for (const Edge &v : g_.adjacency[last_id]) {
             if (!fresh && last_orient != v.from_orient) continue;                         // :137
             const uint32_t allowed = allowance_[v.to];
@@ -498,14 +523,25 @@ private:
             // times this node was stepped on so far; ids compare with the
             // orientation bit masked off (path[0] may still carry the '0' flag)
             uint32_t used = 0;
-            for (size_t i = 1; i < n; ++i) used += ((uint32_t)e.path[i] >> 1) == v.to;
+            {   // (steps after the first are plain (id << 1) | minus: a loop the compiler vectorises)
+                const int32_t *pp = ep.data();
+                const int32_t want = (int32_t)(v.to << 1);
+                for (size_t i = 1; i < n; ++i) used += (uint32_t)((pp[i] & ~1) == want);
+            }
             if (used >= allowed) continue;
-            const bool seen = used > 0 || ((uint32_t)(e.path[0] & ~GFAL_STEP_OTHER) >> 1) == v.to;
+            const bool seen = used > 0 || ((uint32_t)(ep[0] & ~GFAL_STEP_OTHER) >> 1) == v.to;
             auto c = std::make_unique<Node>();
-            c->path.reserve(n + 1);
-            c->path = e.path;
-            if (fresh) c->path.back() = (int32_t)(last_id << 1) | (v.from_orient == '-');   // :148-149
-            c->path.push_back((int32_t)(v.to << 1) | (v.to_orient == '-'));
+            const int32_t step = (int32_t)(v.to << 1) | (v.to_orient == '-');
+            if (fresh) {          // the source takes the orientation of the edge it leaves by (:148-149)
+                std::vector<int32_t> p(ep);
+                p.back() = (int32_t)(last_id << 1) | (v.from_orient == '-');
+                p.push_back(step);
+                c->set_path(std::move(p));
+            } else {
+                c->base = e.full;
+                c->last = step;
+                c->len = (uint32_t)n + 1;
+            }
             c->uniques = e.uniques + (seen ? 0u : 1u);                                    // :153-160
             c->at_destination = v.to == dest_uid_;
             e.kids.push_back(std::move(c));
@@ -553,23 +589,23 @@ private:
                     // search mode: a kid is scored from its parent when the parent is long
                     // enough (no alignment longer than it) and is on the devices -- kept
                     // there by an earlier batch, or itself a child of this one
-                    const bool from_parent = incr_ && e->path.size() >= min_parent_ &&
-                                             !(e->path.back() & GFAL_STEP_OTHER) &&
+                    const bool from_parent = incr_ && e->len >= min_parent_ &&
+                                             !(e->last & GFAL_STEP_OTHER) &&
                                              (e->slot >= 0 || e->batch_at > 0);
                     for (auto &c : e->kids) {
-                        if (incr_ && !c->at_destination && c->path.size() < GFAL_MAX_STEPS &&
-                            c->path.size() >= min_parent_)
+                        if (incr_ && !c->at_destination && c->len < GFAL_MAX_STEPS && c->len >= min_parent_)
                             c->slot = take_slot();
                         if (from_parent) {
                             // (batch_at > 0: the parent is entry batch_at - 1 of this very sub-batch)
                             ch_parent_.push_back(e->batch_at > 0 ? ~(e->batch_at - 1) : e->slot);
-                            ch_step_.push_back(c->path.back());
+                            ch_step_.push_back(c->last);
                             ch_slot_.push_back(c->slot);
-                            ch_max_len_ = std::max(ch_max_len_, (int32_t)c->path.size());
+                            ch_max_len_ = std::max(ch_max_len_, (int32_t)c->len);
                             c->batch_at = (int32_t)ch_parent_.size();
                             c->batch_depth = e->batch_at > 0 ? e->batch_depth + 1 : 0;
                         } else {
-                            batch_steps_.insert(batch_steps_.end(), c->path.begin(), c->path.end());
+                            const std::vector<int32_t> &cp = c->path();
+                            batch_steps_.insert(batch_steps_.end(), cp.begin(), cp.end());
                             batch_off_.push_back((int32_t)batch_steps_.size());
                             batch_slots_.push_back(c->slot);
                             c->batch_at = -(int32_t)batch_slots_.size();
@@ -580,7 +616,7 @@ private:
                 // (a chain of in-batch parents is walked by one device thread per child:
                 // beyond 48 levels the rest of the dive waits for the next batch)
                 for (auto &c : e->kids)
-                    if (!c->at_destination && c->path.size() < GFAL_MAX_STEPS && c->batch_depth < 48)
+                    if (!c->at_destination && c->len < GFAL_MAX_STEPS && c->batch_depth < 48)
                         next_.push_back(c.get());
             }
             level_.swap(next_);
@@ -589,7 +625,7 @@ private:
             std::vector<int32_t> off{0}, steps;
             for (Node *e : batch_parents_)
                 for (auto &c : e->kids) {
-                    steps.insert(steps.end(), c->path.begin(), c->path.end());
+                    steps.insert(steps.end(), c->path().begin(), c->path().end());
                     off.push_back((int32_t)steps.size());
                 }
             const int32_t head[2] = {(int32_t)n_paths, (int32_t)steps.size()};
