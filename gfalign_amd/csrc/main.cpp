@@ -714,9 +714,10 @@ int main(int argc, char **argv)
         if (verbose_flag)
             fprintf(stderr,
                     "time: read %.3f s, pack %.3f s, scorer %.3f s, search %.3f s (candidates %.3f s, "
-                    "scoring %.3f s)\n",
+                    "scoring %.3f s, of which %.3f s making %llu extensions ahead)\n",
                     t_read - t_start, t_pack - t_read, t_open - t_pack, gfal::now_s() - t_open,
-                    search.collect_seconds(), search.score_seconds());
+                    search.collect_seconds(), search.score_seconds(), search.ahead_seconds(),
+                    (unsigned long long)search.made_ahead());
         if (verbose_flag && scorer.n_shards() > 1)
             fprintf(stderr, "%zu devices, per-path counters summed %s\n", scorer.n_shards(),
                     scorer.uses_rccl() ? "by an RCCL all-reduce" : "on the host");

@@ -5803,6 +5803,22 @@ int gfal_group_score_children_begin(gfal_group *g, int32_t n, const int32_t *par
     return no_throw([&] { return group_children_impl(g, n, parent, step, slot, max_path_len); });
 }
 
+int gfal_group_score_poll(gfal_group *g)
+{
+    if (!g) return GFAL_E_ARG;
+    if (!g->pending) return 1;
+    for (gfal_scorer *s : g->shards) {
+        (void)hipSetDevice(s->device);
+        const hipError_t e = hipStreamQuery(s->stream);
+        if (e == hipErrorNotReady) return 0;
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return 1;                   // (gfal_group_score_end reports it)
+        }
+    }
+    return 1;
+}
+
 int gfal_group_score_end(gfal_group *g, uint32_t *bad, uint32_t *good, uint32_t *unaligned)
 {
     if (!g || !bad || !good) return GFAL_E_ARG;

@@ -290,6 +290,8 @@ public:
         }
         return true;
     }
+    // the batch in flight has finished on the devices (never blocks)
+    bool done() const { return n_aln_ == 0 || !group_ || gfal_group_score_poll(group_) != 0; }
     bool begin_children(const std::vector<int32_t> &parent, const std::vector<int32_t> &step,
                         const std::vector<int32_t> &slot, int32_t max_len)
     {
@@ -452,6 +454,8 @@ public:
     uint64_t prefetch_hits() const { return prefetch_hits_; }
     uint64_t prefetch_misses() const { return prefetch_misses_; }
     double collect_seconds() const { return t_collect_; }
+    double ahead_seconds() const { return t_ahead_; }
+    uint64_t made_ahead() const { return made_ahead_; }
     double score_seconds() const { return t_score_; }
 
 private:
@@ -490,6 +494,7 @@ private:
         bool at_destination = false;
         bool scored = false;            // bad / good are known (queue entries, finished batches)
         bool kids_made = false, kids_scored = false;
+        bool kids_batched = false;      // the extensions have been handed to a batch
         std::vector<std::unique_ptr<Node>> kids;   // extensions, adjacency order
         // search mode: where the path is kept on the devices (-1: nowhere), and where
         // the entry sits in the batch being collected (>= 0: the children sub-batch,
@@ -583,8 +588,9 @@ private:
             next_.clear();
             for (Node *e : level_) {
                 if (n_paths >= budget && e != front) break;
-                if (!e->kids_made) {
-                    make_kids(*e);
+                if (!e->kids_batched) {
+                    if (!e->kids_made) make_kids(*e);     // (often made already: see make_ahead)
+                    e->kids_batched = true;
                     batch_parents_.push_back(e);
                     // search mode: a kid is scored from its parent when the parent is long
                     // enough (no alignment longer than it) and is on the devices -- kept
@@ -651,10 +657,11 @@ private:
                 !(scorer_.begin_store(batch_off_, batch_steps_, batch_slots_) && scorer_.end(bad_, good_)))
                 return false;
             full_scored_ += batch_off_.size() - 1;
-            if (!ch_parent_.empty() &&
-                !(scorer_.begin_children(ch_parent_, ch_step_, ch_slot_, ch_max_len_) &&
-                  scorer_.end(ch_bad_, ch_good_)))
-                return false;
+            if (!ch_parent_.empty()) {
+                if (!scorer_.begin_children(ch_parent_, ch_step_, ch_slot_, ch_max_len_)) return false;
+                make_ahead();
+                if (!scorer_.end(ch_bad_, ch_good_)) return false;
+            }
             results_ready_ = true;
         } else if (!scorer_.begin(batch_off_, batch_steps_, true)) {     // :162
             return false;
@@ -663,6 +670,29 @@ private:
         in_flight_ = true;
         t_score_ += now_s() - t0;
         return true;
+    }
+
+    // While the devices score the batch: the extensions of its candidates (the search
+    // mostly dives, so these are what the next batch asks for) are made now -- an
+    // extension needs its parent's path, not its counters -- until the devices are done.
+    // Work that would otherwise sit between two scoring calls; what is never asked for
+    // is only memory.
+    void make_ahead()
+    {
+        const double t0 = now_s();
+        unsigned since_poll = 0;
+        for (Node *e : batch_parents_) {
+            for (auto &c : e->kids) {
+                if (c->kids_made || c->at_destination || c->len >= GFAL_MAX_STEPS) continue;
+                if (since_poll++ % 8 == 0 && scorer_.done()) {      // (a poll costs about as much as an extension)
+                    t_ahead_ += now_s() - t0;
+                    return;
+                }
+                make_kids(*c);
+                ++made_ahead_;
+            }
+        }
+        t_ahead_ += now_s() - t0;
     }
 
     bool finish()
@@ -733,7 +763,8 @@ private:
     std::vector<uint32_t> allowance_;
     std::map<Key, std::unique_ptr<Node>> queue_;
     uint64_t seq_ = 0, scored_ = 0, batches_ = 0;
-    double t_collect_ = 0, t_score_ = 0;
+    double t_collect_ = 0, t_score_ = 0, t_ahead_ = 0;
+    uint64_t made_ahead_ = 0;
     // the batch being collected, and the parents of the one the devices are scoring
     std::vector<Node *> batch_parents_, flight_parents_, level_, next_;
     uint64_t prefetch_hits_ = 0, prefetch_misses_ = 0;

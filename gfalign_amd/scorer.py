@@ -67,6 +67,7 @@ EXPORTS = {
                                         _u32p, _u32p, _u32p]),
     "gfal_group_score_begin": (ctypes.c_int, [ctypes.c_void_p, _i32p, _i32p, ctypes.c_int32, ctypes.c_int]),
     "gfal_group_score_end": (ctypes.c_int, [ctypes.c_void_p, _u32p, _u32p, _u32p]),
+    "gfal_group_score_poll": (ctypes.c_int, [ctypes.c_void_p]),
     "gfal_group_store_reserve": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64]),
     "gfal_group_score_store_begin": (ctypes.c_int, [ctypes.c_void_p, _i32p, _i32p, ctypes.c_int32, _i32p]),
     "gfal_group_score_children_begin": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, _i32p, _i32p, _i32p,

@@ -199,6 +199,10 @@ int  gfal_group_score_begin(gfal_group *g,
                             const int32_t *path_off, const int32_t *path_steps,
                             int32_t n_paths, int filter);
 int  gfal_group_score_end(gfal_group *g, uint32_t *bad, uint32_t *good, uint32_t *unaligned);
+/* 1 if the batch handed over by a _begin call has finished on every device (or none
+   is in flight), 0 if not yet; never blocks.  `gfalign search` generates the next
+   level of candidates until this says 1. */
+int  gfal_group_score_poll(gfal_group *g);
 
 /*
  * Search mode: a candidate scored from its parent.  `gfalign search` only ever
