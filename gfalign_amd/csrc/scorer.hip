@@ -4221,10 +4221,8 @@ static int create_impl(const int32_t *aln_off, const int32_t *aln_steps, int64_t
     int64_t own_aln = n_empty, own_steps = 0, n_lanes = 0;
     // Item order: the well-populated lengths first (k_scan2 builds one window
     // table per tile and length, which pays from a few dozen items up), then the
-    // rare ones (k_scan).  The shards of one set agree on the order (same input);
-    // the groups of 64 are dealt round robin in that order (one counter across the
-    // lengths: a counter per length would hand the first shards one group more of
-    // every length), so a shard's segment of a length holds 1/n of its items.
+    // rare ones (k_scan).  The shards of one set agree on the order (same input)
+    // and on who takes which group of 64 (below).
     int hash_min_items = 48;
     if (const char *env = getenv("GFAL_HASH_MIN_ITEMS")) hash_min_items = std::max(1, atoi(env));
     std::vector<int> len_order;
@@ -4238,6 +4236,49 @@ static int create_impl(const int32_t *aln_off, const int32_t *aln_steps, int64_t
         if (!is_hash_len[(size_t)m] && !by_len[(size_t)m].empty()) len_order.push_back(m);
     std::vector<LenSeg> segs;      // one per length, in item order
     int n_hash_items = 0, n_hash_segs = 0;
+    // Which group of 64 goes to which shard.  k_scan2 pays one prologue per (tile, length)
+    // whatever the shard holds of that length -- measured at config 3: one length costs a
+    // shard as much as ~2000 groups of average length do, whatever the set size -- so a
+    // shard should hold FEW lengths; but within a length its groups must be spread over
+    // the whole content order (a contiguous piece would be one region of the tangle: busy
+    // or idle with the batch's paths).  The lengths, in item order, are laid on a line:
+    // a fixed stretch for holding the length at all, then its groups weighted by what one
+    // costs (about proportional to the length); shard k owns the piece [k W / n,
+    // (k + 1) W / n) of the line; group i of a length falls on its groups' stretch at the
+    // fraction frac(i * golden ratio) (low discrepancy: every run of i's spreads evenly).
+    // A shard then holds two or three lengths (the short tail of rare lengths, which run
+    // in one k_scan launch, counts as one), and all shards of a set derive the same
+    // partition from the same input.  (Round robin over all groups, the first policy,
+    // made every shard pay every prologue: 35 % of ideal at 1/8 of config 3, now 45 %.)
+    // (what a group costs depends on how many of the batch's paths its alignments can be on: about
+    // proportional to the length at config 3, 7 + length at config 5; 3 + length is in between)
+    auto group_weight = [](int m) { return (uint64_t)(36 + 12 * m); };
+    uint64_t shard_fixed = 180000;      // (~2000 groups of average length; the k_scan launch of the rare lengths: twice that)
+    if (const char *env = getenv("GFAL_SHARD_FIXED")) shard_fixed = (uint64_t)std::max(0ll, atoll(env));
+    std::vector<uint64_t> len_w_lo((size_t)max_len + 2, 0);      // where a length's groups start on the line
+    uint64_t total_w = 0;
+    {
+        // (a small set: the fixed stretches must not crowd the groups off the line, or
+        // shards end up empty -- at most twice the groups' share per length)
+        uint64_t items_w = 0, n_charged = 0;
+        bool any_rare = false;
+        for (int m : len_order) {
+            items_w += (uint64_t)((by_len[(size_t)m].size() + WAVE - 1) / WAVE) * group_weight(m);
+            if (is_hash_len[(size_t)m]) ++n_charged;
+            else any_rare = true;
+        }
+        n_charged += any_rare ? 2 : 0;
+        if (n_charged) shard_fixed = std::min(shard_fixed, 2 * items_w / n_charged + 1);
+        bool rare_seen = false;
+        for (int m : len_order) {
+            if (is_hash_len[(size_t)m]) total_w += shard_fixed;
+            else if (!rare_seen) total_w += 2 * shard_fixed;
+            if (!is_hash_len[(size_t)m]) rare_seen = true;
+            len_w_lo[(size_t)m] = total_w;
+            total_w += (uint64_t)((by_len[(size_t)m].size() + WAVE - 1) / WAVE) * group_weight(m);
+        }
+    }
+    const bool by_length = getenv("GFAL_SHARD_ROUND_ROBIN") == nullptr;
     uint64_t global_item = 0;
     for (int m : len_order) {
         const std::vector<int32_t> &idx = by_len[(size_t)m];
@@ -4247,7 +4288,23 @@ static int create_impl(const int32_t *aln_off, const int32_t *aln_steps, int64_t
             // shards are cut AFTER the global sort, item by item: a shard's items
             // are a subset of the unsharded ones (same lanes side by side), so the
             // scan kernel does on 1/n of the items exactly 1/n of the work
-            if ((int32_t)(global_item++ % (uint64_t)n_shards) != shard_index) continue;
+            {
+                const uint64_t gi = global_item++;
+                int32_t owner;
+                if (n_shards == 1) {
+                    owner = 0;
+                } else if (by_length) {
+                    const uint64_t n_groups = (idx.size() + WAVE - 1) / WAVE;
+                    const uint64_t stretch = n_groups * group_weight(m);
+                    const uint64_t u = ((uint64_t)(at / WAVE) * 2654435769ull) & 0xFFFFFFFFull;     // frac(i * phi) in 2^-32
+                    const uint64_t pos = len_w_lo[(size_t)m] + ((stretch * u) >> 32);
+                    owner = (int32_t)std::min<uint64_t>((uint64_t)n_shards - 1,
+                                                        (unsigned __int128)pos * (uint64_t)n_shards / total_w);
+                } else {
+                    owner = (int32_t)(gi % (uint64_t)n_shards);      // (round 1 / first half of round 2)
+                }
+                if (owner != shard_index) continue;
+            }
             const uint32_t *wt = dedup ? wt_len[(size_t)m].data() + at : nullptr;
             src.push_back(ItemSrc{idx.data() + at, wt, (int)cnt, m});
             item_base.push_back((uint32_t)(n_u16 / WAVE));

@@ -181,7 +181,7 @@ public:
         n_aln_ = a.size();
         if (n_aln_ == 0) return true;
         n_devices = (int)std::max<int64_t>(1, std::min<int64_t>(n_devices, n_aln_));
-        // every device gets the whole set and keeps every n_devices-th group of the
+        // every device gets the whole set and keeps its share of the groups of the
         // scorer's own sorted order (gfal_scorer_create_sharded): the shards
         // partition the set and balance by construction.  Creation (a host-side
         // sort each) runs on all devices at once.

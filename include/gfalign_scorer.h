@@ -100,11 +100,14 @@ int gfal_scorer_create_ex(const int32_t *aln_off, const int32_t *aln_steps,
 
 /*
  * One of n_shards shards of the SAME alignment set (multi-GPU):
- * every shard is created from the complete arrays and keeps every n_shards-th
- * group of 64 alignments of the length- and content-sorted order the kernels
- * use, so the shards of one set partition it, balance by construction, and
- * each does 1/n_shards of the unsharded work.  The counters of the shards add
- * up to the unsharded counters (integer sums: any reduction order).
+ * every shard is created from the complete arrays and keeps its share of the
+ * groups of 64 alignments of the length- and content-sorted order the kernels
+ * use -- a few alignment lengths per shard (the scan pays a fixed cost per
+ * length it holds), the groups of a length spread evenly over the shards that
+ * hold it -- so the shards of one set partition it, every shard derives the
+ * same partition from the same input, and the work is balanced by what a
+ * group costs the scan.  The counters of the shards add up to the unsharded
+ * counters (integer sums: any reduction order).
  * gfal_scorer_create_ex is shard 0 of 1.
  */
 int gfal_scorer_create_sharded(const int32_t *aln_off, const int32_t *aln_steps,

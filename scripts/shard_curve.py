@@ -24,7 +24,9 @@ for p in pick:
 soff = np.asarray(soff, np.int32); sst = np.concatenate(sst).astype(np.int32)
 base = {}
 for world in (1, 2, 4, 8):
-    with Scorer(t.aln_off, t.aln_steps, t.V, shard=(0, world)) as sc:
+  worst = {"big": 0.0, "small": 0.0}
+  for k in range(world):          # every shard in turn: the slowest one is the N-GPU step
+    with Scorer(t.aln_off, t.aln_steps, t.V, shard=(k, world)) as sc:
         for _ in range(3):
             sc.score_device(d_off.data_ptr(), d_st.data_ptr(), P, int(t.path_off[-1]), mx, True, d_cnt.data_ptr(), stream.cuda_stream)
         torch.cuda.synchronize()
@@ -39,7 +41,10 @@ for world in (1, 2, 4, 8):
         for _ in range(50):
             sc.evaluate_paths(soff, sst, True)
         small = (time.perf_counter() - t0) / 50 * 1e3
-    if world == 1:
-        base = {"big": big, "small": small}
-    print("1/%d of the alignments: 10 000-path step %.3f ms (%.0f %% of ideal 1/%d), 128-path blocking call %.3f ms (%.0f %%)" % (
-        world, big, 100 * base["big"] / world / big, world, small, 100 * base["small"] / world / small), flush=True)
+    worst["big"] = max(worst["big"], big)
+    worst["small"] = max(worst["small"], small)
+  big, small = worst["big"], worst["small"]
+  if world == 1:
+      base = {"big": big, "small": small}
+  print("1/%d of the alignments (slowest shard): 10 000-path step %.3f ms (%.0f %% of ideal 1/%d), 128-path blocking call %.3f ms (%.0f %%)" % (
+      world, big, 100 * base["big"] / world / big, world, small, 100 * base["small"] / world / small), flush=True)

