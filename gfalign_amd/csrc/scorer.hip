@@ -2499,6 +2499,7 @@ struct DpArgs {
     // list of its path's first node, and the per-path bitmaps over that list in the
     // store that remember which entries the DP accepted (k_child inherits them)
     const uint32_t *sorted_pos;
+    uint32_t *status;           // (k_dp_small: asks for the call to be run again the long way)
     uint32_t *bits;
     uint32_t bits_words;
     const int32_t *q_slot;      // image slot -> store slot or -1
@@ -2713,11 +2714,12 @@ struct DpSysLds {
     static constexpr int BYTES = ENTRIES * (2 * ROWLEN * 2 + 2 * (ROW_WORDS + 2) * 4);
 };
 
-// block `block` of `n_blocks` of the wavefront DP over its length class; always = the
-// class is this function's whatever its size (k_dp_small)
+// block `block` of `n_blocks` of the wavefront DP over its length class.  whole (k_dp_small):
+// the list is short and NOT sorted -- every entry of it with min_m <= m <= MC is this
+// function's, wherever it sits
 template <int MC>
 __device__ __forceinline__ void dp_sys_body(const DpArgs &a, uint32_t block, uint32_t n_blocks,
-                                            unsigned char *smem, bool always)
+                                            unsigned char *smem, bool whole, int min_m)
 {
     static_assert(MC == 4 || MC == 8 || MC == 16 || MC == 64, "group inside a DPP row, or the wave");
     // MC < 64: an entry takes two neighbouring groups, one per orientation;
@@ -2736,9 +2738,9 @@ __device__ __forceinline__ void dp_sys_body(const DpArgs &a, uint32_t block, uin
     // MC = 4, 8, 16: classes 0, 1, 2; MC = 64: class 3 and the entries of the last
     // class that fit (k_dp_long skips those on a short list)
     constexpr int CLS = MC == 4 ? 0 : MC == 8 ? 1 : MC == 16 ? 2 : 3;
-    if (!always && !wavefront_class(a, total, CLS)) return;       // many entries: k_dp_regs / k_dp_long
-    const uint32_t lo = min(a.class_lo[CLS], total);
-    const uint32_t hi = MC == 64 ? total : min(a.class_lo[CLS + 1], total);
+    if (!whole && !wavefront_class(a, total, CLS)) return;        // many entries: k_dp_regs / k_dp_long
+    const uint32_t lo = whole ? 0u : min(a.class_lo[CLS], total);
+    const uint32_t hi = (whole || MC == 64) ? total : min(a.class_lo[CLS + 1], total);
     const int lane = threadIdx.x;
     const int c = lane % MC, g = lane / MC;
     const int en = MC == 64 ? 0 : g / 2;                  // my entry of the wave
@@ -2746,7 +2748,7 @@ __device__ __forceinline__ void dp_sys_body(const DpArgs &a, uint32_t block, uin
     for (uint32_t w0 = lo + block * ENTRIES; w0 < hi; w0 += n_blocks * ENTRIES) {
         const uint32_t w = w0 + en;
         const DpEntry e = load_entry(a, w, w < hi);
-        const bool live = w < hi && e.m <= MC;
+        const bool live = w < hi && e.m <= MC && e.m >= min_m;
         // stage the groups' paths with the whole wave, all loads of a path in
         // flight at once; neighbouring groups usually share the path (the two
         // orientations of an entry always do) and then share the copy
@@ -2892,25 +2894,34 @@ template <int MC>
 __global__ __launch_bounds__(DP_THREADS) void k_dp_sys(DpArgs a)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[DpSysLds<MC>::BYTES];
-    dp_sys_body<MC>(a, blockIdx.x, gridDim.x, smem, false);
+    dp_sys_body<MC>(a, blockIdx.x, gridDim.x, smem, false, 0);
 }
 
 // The search's batches leave the exact DP a few hundred to a few thousand pairs in all:
 // one launch for every length class (grid.y) instead of a fork over four streams with a
-// wavefront and a register kernel each, most of which find an empty or short list.
+// wavefront and a register kernel each, most of which find an empty or short list --
+// and straight from the list as k_child pushed it: every class walks the whole list and
+// takes its own entries, so the counting sort (two more launches) is not needed.
 // The host picks it when the previous call's list was short (and no alignment is
 // longer than a wave); a longer list than expected is still decided exactly, only
-// more slowly than the register kernels would.
+// more slowly than the sort and the register kernels would.
 __global__ __launch_bounds__(DP_THREADS) void k_dp_small(DpArgs a)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[DpSysLds<4>::BYTES];      // the largest of the four
     static_assert(DpSysLds<4>::BYTES >= DpSysLds<8>::BYTES && DpSysLds<4>::BYTES >= DpSysLds<16>::BYTES &&
                       DpSysLds<4>::BYTES >= DpSysLds<64>::BYTES, "LDS of k_dp_small");
+    // the list turned out long after all (every class would walk all of it): report it
+    // like a list that did not fit -- the blocking call runs the batch again, and with
+    // this call's count on record it takes the sort and the register kernels
+    if (*a.wl_count > 32768ull && *a.wl_count <= a.wl_capacity) {
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) atomicOr(a.status, ST_DP_OVERFLOW);
+        return;
+    }
     switch (blockIdx.y) {
-    case 0: dp_sys_body<4>(a, blockIdx.x, gridDim.x, smem, true); break;
-    case 1: dp_sys_body<8>(a, blockIdx.x, gridDim.x, smem, true); break;
-    case 2: dp_sys_body<16>(a, blockIdx.x, gridDim.x, smem, true); break;
-    default: dp_sys_body<64>(a, blockIdx.x, gridDim.x, smem, true); break;
+    case 0: dp_sys_body<4>(a, blockIdx.x, gridDim.x, smem, true, 1); break;
+    case 1: dp_sys_body<8>(a, blockIdx.x, gridDim.x, smem, true, 5); break;
+    case 2: dp_sys_body<16>(a, blockIdx.x, gridDim.x, smem, true, 9); break;
+    default: dp_sys_body<64>(a, blockIdx.x, gridDim.x, smem, true, 17); break;
     }
 }
 
@@ -5007,33 +5018,36 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
                                cx->d_g1_tmp);
         if (s->profiling) HIP_TRY(hipEventRecord(ev[2], st));
 
-        hipLaunchKernelGGL(k_wl_offsets, dim3(N_CLASSES), dim3(1024), 0, st, d_hist, d_offsets,
-                           d_cursor, d_class_lo + 8, (int)n_paths);
-        hipLaunchKernelGGL(k_wl_scatter, dim3(256), dim3(256), 0, st, a.items,
-                           s->d_worklist, a.wl_count, s->wl_capacity, d_offsets,
-                           d_cursor, (uint32_t)n_paths, s->d_worklist_sorted, d_class_lo + 8, d_class_lo,
-                           inherit ? s->d_wl_pos : nullptr, s->d_wl_pos_sorted);
+        // a search's batches: a short list last time (and no alignment longer than a wave)
+        // -> one launch runs every DP class, on the list as it was pushed
+        static const bool dp_small_off = getenv("GFAL_DP_SMALL") != nullptr && atoi(getenv("GFAL_DP_SMALL")) == 0;
+        const bool dp_small = children && !dp_small_off && prev_dp_pairs >= 0 && prev_dp_pairs <= 16384 &&
+                              s->max_aln_len <= 64;
+        if (!dp_small) {
+            hipLaunchKernelGGL(k_wl_offsets, dim3(N_CLASSES), dim3(1024), 0, st, d_hist, d_offsets,
+                               d_cursor, d_class_lo + 8, (int)n_paths);
+            hipLaunchKernelGGL(k_wl_scatter, dim3(256), dim3(256), 0, st, a.items,
+                               s->d_worklist, a.wl_count, s->wl_capacity, d_offsets,
+                               d_cursor, (uint32_t)n_paths, s->d_worklist_sorted, d_class_lo + 8, d_class_lo,
+                               inherit ? s->d_wl_pos : nullptr, s->d_wl_pos_sorted);
+        }
         DpArgs d;
         d.items = a.items;
         d.images = s->d_images;
         d.L = L;
         d.n_paths = n_paths;
-        d.sorted = s->d_worklist_sorted;
+        d.sorted = dp_small ? s->d_worklist : s->d_worklist_sorted;
         d.class_lo = d_class_lo;
         d.wl_count = a.wl_count;
         d.wl_capacity = s->wl_capacity;
         d.sys_limit = s->dp_sys_limit;
         d.row_scratch = s->d_rows;
         d.counts = d_counts;
-        d.sorted_pos = inherit ? s->d_wl_pos_sorted : nullptr;
+        d.sorted_pos = inherit ? (dp_small ? s->d_wl_pos : s->d_wl_pos_sorted) : nullptr;
+        d.status = s->d_status;
         d.bits = inherit ? s->d_st_bits : nullptr;
         d.bits_words = s->bits_words;
         d.q_slot = inherit ? cx->batch.slot : nullptr;
-        // a search's batches: a short list last time (and no alignment longer than a wave)
-        // -> one launch for all classes
-        static const bool dp_small_off = getenv("GFAL_DP_SMALL") != nullptr && atoi(getenv("GFAL_DP_SMALL")) == 0;
-        const bool dp_small = children && !dp_small_off && prev_dp_pairs >= 0 && prev_dp_pairs <= 16384 &&
-                              s->max_aln_len <= 64;
         if (dp_small)
             hipLaunchKernelGGL(k_dp_small, dim3(512, 4), dim3(DP_THREADS), 0, st, d);
         // fork: classes 8 / 16 / 32+ on side streams, class 4 on the caller's
