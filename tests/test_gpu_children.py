@@ -257,3 +257,34 @@ def test_bad_batches_are_refused(gpu):
         # and the scorer still works
         _, full, res = tree.children([(("slot", slots[1]), walk[m + 2])], keep=False)
         assert_same(res, expect(alns, full), "after the refusals")
+
+
+def test_short_list_dp_kernel_hands_a_long_list_back(gpu):
+    """After a call with a short exact-DP list the next children call runs one DP launch
+    on the unsorted list (k_dp_small); if its own list turns out long, the kernel reports
+    it and the blocking call runs the batch again with the sort and the register
+    kernels.  45 000 two-step alignments [v, a0] are start-overhang candidates of every
+    path through v that starts with a0: a chain of 40 new nodes makes 130 000 pairs."""
+    a0 = 0
+    alns = []
+    for v in range(1, 301):
+        alns += [[(v << 1), (a0 << 1)]] * 150
+    alns += [[(a0 << 1), (1 << 1)], [(2 << 1) | 1, (1 << 1) | 1]] * 3
+    aoff, ast = csr(alns)
+    with Scorer(aoff, ast, 512) as sc, Group([sc]) as g:
+        tree = Tree(g, 128)
+        root = [(a0 << 1), (1 << 1), (2 << 1)]
+        slots, res = tree.store([root])
+        assert_same(res, expect(alns, [root]), "root")
+        _, full, res = tree.children([(("slot", slots[0]), (400 << 1))], keep=False)     # a short list
+        assert_same(res, expect(alns, full), "short list")
+        before = sc.info()["n_overflow_reruns"]
+        batch = [(("slot", slots[0]), (3 << 1))]
+        for k in range(1, 40):
+            batch.append((("batch", k - 1), ((3 + k) << 1)))
+        _, full, res = tree.children(batch, keep=False)
+        assert_same(res, expect(alns, full), "long list")
+        info = sc.info()
+        assert info["dp_pairs"] > 32768 and info["n_overflow_reruns"] == before + 1
+        _, full, res = tree.children(batch[:5], keep=False)                               # and on it goes
+        assert_same(res, expect(alns, full), "after the re-run")
