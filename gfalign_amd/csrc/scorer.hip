@@ -3390,14 +3390,24 @@ __global__ __launch_bounds__(CHILD_THREADS) void k_child(ChildArgs a)
     const bool remember = a.wl_pos != nullptr;
     const int root = a.b.root[child], my_slot = a.b.slot[child];
     const bool can_inherit = remember && root >= 0 && a.b.st_bitsok[root] != 0;
-    uint32_t *tail = reinterpret_cast<uint32_t *>(lid + a.L.nm);      // [v2 / 32] nodes of the path's tail
+    // one node mask of the path's tail per DP length class: an alignment of m steps looks at
+    // the last m + depth steps, its class's longest member stands in for m (4, 8, 16, 32,
+    // the longest alignment): short alignments, the bulk, look at a short tail
+    uint32_t *tail = reinterpret_cast<uint32_t *>(lid + a.L.nm);      // [N_CLASSES][v2 / 32]
+    const int tail_words = (a.L.v2 + 31) / 32;
     if (can_inherit) {
-        for (int i = tid; i < (a.L.v2 + 31) / 32; i += CHILD_THREADS) tail[i] = 0;
+        for (int i = tid; i < N_CLASSES * tail_words; i += CHILD_THREADS) tail[i] = 0;
         __syncthreads();
-        const int from = max(0, n - (a.max_aln_len + a.b.depth[child]));
+        const int depth = a.b.depth[child];
+        const int from = max(0, n - (a.max_aln_len + depth));
         for (int p = from + tid; p < n; p += CHILD_THREADS) {
             const uint32_t v = lds_u16(lid32, (uint32_t)p);
-            if (v != ENT_NONE) atomicOr(&tail[v >> 5], 1u << (v & 31u));
+            if (v == ENT_NONE) continue;
+            const int back = n - p;          // 1 = the path's last step
+            for (int c = 0; c < N_CLASSES; ++c) {
+                const int reach = (c == LONG_CLASS ? a.max_aln_len : (4 << c)) + depth;
+                if (back <= reach) atomicOr(&tail[c * tail_words + (int)(v >> 5)], 1u << (v & 31u));
+            }
         }
         __syncthreads();
     }
@@ -3449,9 +3459,10 @@ __global__ __launch_bounds__(CHILD_THREADS) void k_child(ChildArgs a)
                 slot = ent.x;
                 m = load_B(ent);
                 bool inherit = can_inherit;
+                const uint32_t *my_tail = tail + length_class(m) * tail_words;
                 for (int t = 0; t < m && inherit; ++t) {
                     const uint32_t v = B(t) >> 1;
-                    inherit = ((tail[v >> 5] >> (v & 31u)) & 1u) == 0u;
+                    inherit = ((my_tail[v >> 5] >> (v & 31u)) & 1u) == 0u;
                 }
                 if (inherit) {
                     inh_bit = ((pbits[pos >> 5] >> (pos & 31u)) & 1u) != 0u;
@@ -4847,7 +4858,7 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
             int chunks = std::max(1, std::min(32, 8 * s->n_cus / (int)n_paths));
             if (const char *env = getenv("GFAL_CHILD_CHUNKS")) chunks = std::max(1, atoi(env));
             const size_t lds_c = img_bytes + (size_t)L.nm * sizeof(uint16_t) +
-                                 (size_t)((L.v2 + 31) / 32) * sizeof(uint32_t);
+                                 (size_t)N_CLASSES * ((L.v2 + 31) / 32) * sizeof(uint32_t);
             if (lds_c > (size_t)LDS_MAX - CHILD_STATIC_LDS) {
                 set_err("%d local nodes exceed the LDS budget of the children kernel", s->n_local);
                 return GFAL_E_RANGE;
