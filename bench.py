@@ -365,6 +365,12 @@ def main():
                 "valu_wave_insts_per_step": issue["valu_wave_insts_per_step"] if issue else None,
                 "salu_wave_insts_per_step": issue["salu_wave_insts_per_step"] if issue else None,
                 "peak_vop3_class": (peaks["valu_vop3_ginst_per_s_simd"] * peaks["n_simds"]) if peaks else None,
+                # the same against the measured rate of a synthetic loop with the scan's own mix
+                # (4 VALU : 2 SALU : 1/8 LDS, tools/valu_rate.hip): how close the kernel is to what
+                # its instruction mix can issue at all; `frac` above is against simple two-operand ops
+                "peak_scan_mix": (peaks["valu_scan_mix_ginst_per_s_simd"] * peaks["n_simds"]) if peaks else None,
+                "frac_of_scan_mix_peak": (achieved / (peaks["valu_scan_mix_ginst_per_s_simd"] * peaks["n_simds"]))
+                                         if (achieved and peaks) else None,
                 "hbm_algorithmic_bytes_per_launch": alg_bytes,
                 "hbm_algorithmic_gbs": alg_gbs,
                 "hbm_algorithmic_frac_of_8tbs": (alg_gbs / HBM_PEAK_GBS) if alg_gbs else None,
