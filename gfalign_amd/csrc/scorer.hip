@@ -11,11 +11,15 @@
 //   k_prep      one wave per candidate path: builds the path's lookup image
 //               (first-occurrence table by node, occurrence chain, steps) in
 //               LDS and writes it to HBM; also the `unaligned` counter.
-//   k_scan      workgroup = T path images staged in LDS x one chunk of items;
-//               one lane per alignment, its steps in registers, reused across
-//               the T paths; ballot/popcount per (wave, path); one atomic per
-//               counter per workgroup.  Pairs the cheap rules cannot decide
-//               go to a worklist.
+//   k_scan2     the dominant kernel: workgroup = (tile of T <= 8 paths) x (one
+//               alignment length) x (a chunk of its items); every window of the
+//               tile's paths sits in a hash table in LDS, so a lane's alignment
+//               is tested against ALL paths of the tile with one probe.  One
+//               launch per alignment-length group (spill-free instantiations).
+//   k_scan      the same decisions by occurrence-chain walks: workgroup = T path
+//               images staged in LDS x one chunk of items; the rare alignment
+//               lengths and batches of a few dozen paths.  Pairs the cheap rules
+//               of either kernel cannot decide go to a worklist.
 //   k_wl_*      counting sort of the worklist by (length class, path).
 //   k_dp_regs   exact Needleman-Wunsch + traceback-exit propagation for the
 //               worklist ("start-overhang" pairs): one pair per lane, rows in
@@ -25,6 +29,10 @@
 //               column per lane: the latency of a single fill decides there.
 //   k_pairs     the same exact DP for every alignment of one path, both
 //               orientations (evalPath's per-alignment scores).
+//   k_child     search mode: a candidate scored from its parent (stored on the
+//               device) through two inverted lists, a content table and the
+//               DP verdicts remembered per stored path; k_dp_small decides what
+//               is left in one launch.
 //
 // No MFMA anywhere: the work is integer compares and LDS table lookups.
 #include <hip/hip_runtime.h>
