@@ -3101,9 +3101,13 @@ __global__ __launch_bounds__(1024) void k_inv_scan(const uint32_t *__restrict__ 
 }
 
 // one thread per lane: enter its alignment into the content table
+// rec[idx] = {representative lane, m | step 0 << 16, steps 1..2, steps 3..4}: what a lookup
+// compares in one 16-byte load (k_tile); lane_key[lane] = idx, the identity of the lane's
+// content (k_scan3)
 __global__ void k_ct_build(Items items, const int32_t *__restrict__ slot_orig, uint32_t n_slots,
                            const uint32_t *__restrict__ item_hash, uint32_t *__restrict__ key,
-                           uint32_t *__restrict__ hash, uint32_t *__restrict__ mult, uint32_t mask)
+                           uint32_t *__restrict__ hash, uint32_t *__restrict__ mult, uint32_t mask,
+                           uint4 *__restrict__ rec, uint32_t *__restrict__ lane_key)
 {
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= n_slots || slot_orig[slot] < 0) return;
@@ -3115,10 +3119,17 @@ __global__ void k_ct_build(Items items, const int32_t *__restrict__ slot_orig, u
         if (prev == CT_EMPTY) {
             hash[idx] = h;
             atomicAdd(&mult[idx], w);
+            const uint32_t it = slot >> 6;
+            const int m = items.len[it];
+            const uint16_t *bp = items.steps + (size_t)items.base[it] * WAVE + (slot & 63u);
+            auto st = [&](int k) -> uint32_t { return k < m ? (uint32_t)bp[(size_t)k * WAVE] : 0u; };
+            rec[idx] = make_uint4(slot, (uint32_t)m | (st(0) << 16), st(1) | (st(2) << 16), st(3) | (st(4) << 16));
+            lane_key[slot] = idx;
             return;
         }
         if (item_hash[prev] == h && lane_same_content(items, prev, slot)) {
             atomicAdd(&mult[idx], w);
+            lane_key[slot] = idx;
             return;
         }
         idx = (idx + 1u) & mask;
@@ -3637,6 +3648,792 @@ __global__ __launch_bounds__(256) void k_store_paths(const int32_t *__restrict__
         if (st_bitsok) st_bitsok[slot] = 0;     // (the scan kernels do not know list positions)
     }
 }
+
+// --------------------------------------------------------------------------
+// k_tile + k_scan3 (round 3): the subpath test by content identity.
+//
+// k_scan2 finds an alignment among a tile's windows through a hash of its steps
+// and then compares the steps themselves with the staged path -- which is why
+// the paths' steps (both strands) live in LDS, why a tile holds 8 paths, and why
+// every (item, tile) visit costs ~125 VALU instructions of which 8 paths share
+// the bill.  Here the comparison of steps is done ONCE per distinct window,
+// against the content table `create` builds over the alignments (one entry per
+// distinct step sequence; the entry's index is the content's identity and every
+// lane carries the index of its own alignment):
+//
+//   k_tile_masks   per tile of T <= 31 paths: the node masks (which tile paths
+//                  carry each node), written to HBM once instead of being
+//                  rebuilt by every workgroup of the tile.
+//   k_tile         per (tile, alignment length M): every M-step window of the
+//                  tile's paths, both strands, is looked up in the content
+//                  table (exact: hash, length, steps); the windows that ARE some
+//                  alignment's content end up as a list of {content index, mask
+//                  of the tile paths that contain it} in HBM.  Windows a path
+//                  shares with the tile's first path (prefixes, siblings) are
+//                  looked up once.
+//   k_scan3        workgroup = (tile, M, chunk of items) as in k_scan2, but its
+//                  prologue only loads the node masks and enters the list into
+//                  an LDS table keyed by content index; per item a lane does its
+//                  node-mask reads (the filter for 31 paths at once), ONE
+//                  probe sequence that ends in an exact key comparison, and
+//                  has the answer for all T paths.  No steps in LDS, no window
+//                  comparison, ~4x the paths per (item, tile) visit.
+//
+// Exactness: two alignments have the same index iff they have the same steps
+// (k_ct_build compares steps), a window gets an index only after its steps were
+// compared with the entry's, and the LDS probe compares full 32-bit indices.
+// --------------------------------------------------------------------------
+constexpr int T3_MAX = 31;                 // tile paths: bits 0..30 of a node mask (bit 31: NOT_A0)
+constexpr int HT_LOG = 13;
+constexpr int HT_SLOTS = 1 << HT_LOG;      // k_tile's own table (dedup of the tile's windows)
+constexpr uint32_t KEY_EMPTY = 0xFFFFFFFFu;
+constexpr int T3_HDR_WORDS = 96;           // per (tile, length): n_passes, then {t0 | t1 << 8, begin, count} per pass
+constexpr int T3_CT_INLINE = 5;            // steps of an alignment a content-table record carries
+
+struct ContentTable {
+    const uint4 *rec;       // {representative lane or CT_EMPTY, m | s0 << 16, s1 | s2 << 16, s3 | s4 << 16}
+    uint32_t mask;
+};
+
+struct TileArgs {
+    Items items;
+    ContentTable ct;
+    const uint16_t *images;
+    ImageLayout L;
+    const uint16_t *lids;
+    int n_paths, tile, tile0;      // tile0: first tile of this launch (slab)
+    const LenSeg *segs;
+    int n_segs;
+    uint32_t cap;                  // entries one k_scan3 pass holds (half its table)
+    uint32_t *tile_masks;          // [tiles of the slab][v2]
+    uint32_t *hdr;                 // [tiles of the slab][n_segs][T3_HDR_WORDS]
+    uint2 *list;                   // [tiles of the slab][n_segs][stride]
+    uint32_t stride;
+};
+
+// which tile paths carry each node (the filter of src/eval.cpp:81-91 as a bit test);
+// bit 31 (NOT_A0) on every node but the one of the tile's first step
+__global__ __launch_bounds__(1024) void k_tile_masks(TileArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds32[];
+    const int tid = threadIdx.x;
+    const int tile = a.tile0 + (int)blockIdx.x;
+    const int path0 = tile * a.tile;
+    const int T = min(a.tile, a.n_paths - path0);
+    const int v2 = a.L.v2, nm = a.L.nm;
+    for (int v = tid; v < v2; v += 1024) lds32[v] = NOT_A0;
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        const uint32_t *lsrc = reinterpret_cast<const uint32_t *>(a.lids + (size_t)(path0 + t) * nm);
+        for (int o = tid; o < nm / 2; o += 1024) {
+            const uint32_t d = lsrc[o];
+            const uint32_t lo = d & 0xFFFFu, hi = d >> 16;
+            if (lo != 0xFFFFu) atomicOr(&lds32[lo], 1u << t);
+            if (hi != 0xFFFFu) atomicOr(&lds32[hi], 1u << t);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t a0 = a.images[(size_t)path0 * a.L.total + a.L.step_at()];
+        if (a0 < STEP_NOMATCH) lds32[a0 >> 1] &= ~NOT_A0;
+    }
+    __syncthreads();
+    uint32_t *dst = a.tile_masks + (size_t)blockIdx.x * v2;
+    for (int v = tid; v < v2; v += 1024) dst[v] = lds32[v];
+}
+
+// index of the content  W[k] = F[dir * k] ^ flip  (k < M) in the content table, or
+// KEY_EMPTY.  w0..w4: its first steps (0xFFFFFFFF beyond M), already in registers.
+__device__ __forceinline__ uint32_t ct_find(const TileArgs &a, uint32_t h, int M, const uint16_t *F,
+                                            int dir, uint32_t flip, const uint32_t (&w)[T3_CT_INLINE])
+{
+    uint32_t idx = h & a.ct.mask;
+    while (true) {
+        const uint4 r = a.ct.rec[idx];
+        if (r.x == CT_EMPTY) return KEY_EMPTY;
+        if ((int)(r.y & 0xFFFFu) == M) {
+            bool eq = (r.y >> 16) == w[0];
+            if (M > 1) eq &= (r.z & 0xFFFFu) == w[1];
+            if (M > 2) eq &= (r.z >> 16) == w[2];
+            if (M > 3) eq &= (r.w & 0xFFFFu) == w[3];
+            if (M > 4) eq &= (r.w >> 16) == w[4];
+            if (eq && M > T3_CT_INLINE) {
+                const uint32_t it = r.x >> 6;
+                const uint16_t *bp = a.items.steps + (size_t)a.items.base[it] * WAVE + (r.x & 63u);
+                for (int k = T3_CT_INLINE; k < M; ++k)
+                    eq &= (uint32_t)bp[(size_t)k * WAVE] == ((uint32_t)F[dir * k] ^ flip);
+            }
+            if (eq) return idx;
+        }
+        idx = (idx + 1u) & a.ct.mask;
+    }
+}
+
+// {key, mask} table in LDS, linear probing; misc[0] counts the entries
+__device__ __forceinline__ void t3_insert(uint32_t *tab, uint32_t *misc, uint32_t key, uint32_t bits,
+                                          uint32_t cap)
+{
+    uint32_t slot = key & (HT_SLOTS - 1u);
+    while (true) {
+        const uint32_t old = atomicCAS(&tab[2u * slot], KEY_EMPTY, key);
+        if (old == KEY_EMPTY) {
+            if (atomicAdd(&misc[0], 1u) + 1u > cap) misc[1] = 1u;
+            break;
+        }
+        if (old == key) break;
+        slot = (slot + 1u) & (HT_SLOTS - 1u);
+    }
+    atomicOr(&tab[2u * slot + 1u], bits);
+}
+
+// the windows (forward start f, M steps) of one tile path, both strands -> the table
+__device__ __forceinline__ void t3_window(const TileArgs &a, uint32_t *tab, uint32_t *misc,
+                                          const uint16_t *Fp, int f, int M, uint32_t bits)
+{
+    const uint16_t *F = Fp + f;
+    uint32_t hf = whash_init(M), hr = hf;
+    uint32_t wf[T3_CT_INLINE], wr[T3_CT_INLINE];
+#pragma unroll
+    for (int k = 0; k < T3_CT_INLINE; ++k) wf[k] = wr[k] = 0xFFFFFFFFu;
+    bool real = true;
+    for (int k = 0; k < M; ++k) {
+        const uint32_t c = F[k], d = (uint32_t)F[M - 1 - k] ^ 1u;
+        real &= c < STEP_NOMATCH;            // a step that equals nothing: no alignment matches
+        hf = whash_step(hf, c);
+        hr = whash_step(hr, d);
+#pragma unroll
+        for (int j = 0; j < T3_CT_INLINE; ++j)
+            if (k == j) {
+                wf[j] = c;
+                wr[j] = d;
+            }
+    }
+    if (!real) return;
+    const uint32_t kf = ct_find(a, whash_final(hf), M, F, 1, 0u, wf);
+    if (kf != KEY_EMPTY) t3_insert(tab, misc, kf, bits, a.cap);
+    const uint32_t kr = ct_find(a, whash_final(hr), M, F + (M - 1), -1, 1u, wr);
+    if (kr != KEY_EMPTY && kr != kf) t3_insert(tab, misc, kr, bits, a.cap);
+}
+
+// the entries whose mask meets `range` -> out[0 ..), masks cut to the range; returns the
+// count (all threads).  misc[2]: cursor.
+__device__ __forceinline__ uint32_t t3_emit(const uint32_t *tab, uint32_t *misc, uint32_t range,
+                                            uint2 *out, int tid)
+{
+    __syncthreads();
+    if (tid == 0) misc[2] = 0;
+    __syncthreads();
+    const int lane = tid & (WAVE - 1);
+    for (int s0 = 0; s0 < HT_SLOTS; s0 += 1024) {
+        const uint32_t key = tab[2 * (s0 + tid)], m = tab[2 * (s0 + tid) + 1] & range;
+        const bool have = key != KEY_EMPTY && m != 0u;
+        const lanemask bm = WAVE_MASK(have);
+        if (bm == 0) continue;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&misc[2], (uint32_t)__popcll(bm));
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (have) out[base + lanes_below(bm, lane)] = make_uint2(key, m);
+    }
+    __syncthreads();
+    return misc[2];
+}
+
+__device__ __forceinline__ void t3_clear(uint32_t *tab, uint32_t *misc, int tid)
+{
+    uint4 *t4 = reinterpret_cast<uint4 *>(tab);
+    for (int i = tid; i < HT_SLOTS / 2; i += 1024) t4[i] = make_uint4(KEY_EMPTY, 0u, KEY_EMPTY, 0u);
+    if (tid < 4) misc[tid] = 0;
+}
+
+constexpr int T3_TILE_LDS = (2 * HT_SLOTS + 3 * 1024 + 32 + 16) * 4;
+
+__global__ __launch_bounds__(1024, 8) void k_tile(TileArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds32[];
+    uint32_t *tab = lds32;                       // [HT_SLOTS] {key, mask}
+    uint32_t *eqbm = tab + 2 * HT_SLOTS;         // [32][32] bit f of row t: step f of path t == step f of the base path
+    uint32_t *shm = eqbm + 1024;                 // [32][32] bit i of [t][j]: window 32 j + i of path t is the base path's
+    uint32_t *wbits = shm + 1024;                // [1024] per window of the base path: the tile paths that share it
+    uint32_t *nlen = wbits + 1024;               // [32]
+    uint32_t *misc = nlen + 32;                  // [0] entries [1] overflow [2] emit cursor
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile_rel = (int)blockIdx.x;
+    const int path0 = (a.tile0 + tile_rel) * a.tile;
+    const int T = min(a.tile, a.n_paths - path0);
+    const LenSeg sg = a.segs[blockIdx.y];
+    const int M = (int)sg.m;
+    uint32_t *hdr = a.hdr + ((size_t)tile_rel * a.n_segs + blockIdx.y) * T3_HDR_WORDS;
+    uint2 *out = a.list + ((size_t)tile_rel * a.n_segs + blockIdx.y) * a.stride;
+    const size_t img_stride = (size_t)a.L.total;
+    const uint16_t *img0 = a.images + (size_t)path0 * img_stride;
+
+    if (tid < 32) nlen[tid] = tid < T ? (uint32_t)img0[(size_t)tid * img_stride + a.L.len_at()] : 0u;
+    t3_clear(tab, misc, tid);
+    __syncthreads();
+    int base = -1;
+    for (int t = 0; t < T; ++t)
+        if (base < 0 && (int)nlen[t] >= M) base = t;
+    if (base < 0) {                              // no tile path has an M-step window
+        if (tid == 0) {
+            hdr[0] = 1;
+            hdr[1] = (uint32_t)T << 8;
+            hdr[2] = 0;
+            hdr[3] = 0;
+        }
+        return;
+    }
+    const int n_b = (int)nlen[base];
+    const uint16_t *Fb = img0 + (size_t)base * img_stride + a.L.step_at();
+
+    // (A) where every path agrees with the base path, one bit per position
+    for (int c = wave; c < T * 16; c += 1024 / WAVE) {
+        const int t = c >> 4, p = (c & 15) * WAVE + lane;
+        const int lim = min((int)nlen[t], n_b);
+        bool eq = false;
+        if (p < lim) eq = img0[(size_t)t * img_stride + a.L.step_at() + p] == Fb[p];
+        const lanemask m = WAVE_MASK(eq);
+        if (lane == 0) {
+            eqbm[t * 32 + (c & 15) * 2] = (uint32_t)m;
+            eqbm[t * 32 + (c & 15) * 2 + 1] = (uint32_t)(m >> 32);
+        }
+    }
+    __syncthreads();
+    // (B1) thread (t, j): which of the windows 32 j .. 32 j + 31 of path t lie where it agrees
+    // with the base path (then the window IS the base path's: entered there)
+    const int q = tid >> 5, j = tid & 31;
+    {
+        uint32_t sh = 0;
+        if (q < T && q != base && (int)nlen[q] >= M) {
+            int nz = 32 * (j + 1);               // next position >= the dword's end where the paths differ
+            for (int jj = j + 1; jj < 32; ++jj) {
+                const uint32_t w = ~eqbm[q * 32 + jj];
+                if (w) {
+                    nz = 32 * jj + __builtin_ctz(w);
+                    break;
+                }
+                nz = 32 * (jj + 1);
+            }
+            const uint32_t w = eqbm[q * 32 + j];
+            for (int i = 31; i >= 0; --i) {
+                if (!((w >> i) & 1u)) nz = 32 * j + i;
+                if (nz >= 32 * j + i + M) sh |= 1u << i;
+            }
+        }
+        shm[q * 32 + j] = sh;
+    }
+    __syncthreads();
+    // (B2) thread (q, j) -> window f = 32 j + q of the base path: who shares it
+    {
+        uint32_t bits = 1u << base;
+        for (int t = 0; t < T; ++t) bits |= ((shm[t * 32 + j] >> q) & 1u) << t;
+        wbits[32 * j + q] = bits;
+    }
+    __syncthreads();
+    // (C) the base path's windows, and of every other path those that are its own
+    {
+        const int f = 32 * j + q;
+        if (f + M <= n_b && misc[1] == 0u) t3_window(a, tab, misc, Fb, f, M, wbits[f]);
+        if (q < T && q != base && (int)nlen[q] >= M) {
+            const int n_t = (int)nlen[q];
+            const uint16_t *Fp = img0 + (size_t)q * img_stride + a.L.step_at();
+            uint32_t u = ~shm[q * 32 + j];
+            while (u) {
+                const int i = __builtin_ctz(u);
+                u &= u - 1u;
+                const int g = 32 * j + i;
+                if (g + M > n_t) break;
+                if (misc[1] != 0u) break;
+                t3_window(a, tab, misc, Fp, g, M, 1u << q);
+            }
+        }
+    }
+    __syncthreads();
+    if (misc[1] == 0u) {                         // everything fits one pass (the usual case)
+        const uint32_t n = t3_emit(tab, misc, 0x7FFFFFFFu, out, tid);
+        if (tid == 0) {
+            hdr[0] = 1;
+            hdr[1] = (uint32_t)T << 8;
+            hdr[2] = 0;
+            hdr[3] = n;
+        }
+        return;
+    }
+    // unrelated paths: path by path, a pass is closed when the next path does not fit
+    // beside it (one path alone always does: <= 2000 windows <= cap)
+    __syncthreads();
+    t3_clear(tab, misc, tid);
+    __syncthreads();
+    int pass_start = 0, n_passes = 0;
+    uint32_t out_pos = 0;
+    for (int t = 0; t <= T; ++t) {
+        bool close = t == T;
+        if (t < T) {
+            const int n_t = (int)nlen[t];
+            const uint16_t *Fp = img0 + (size_t)t * img_stride + a.L.step_at();
+            if (tid + M <= n_t) t3_window(a, tab, misc, Fp, tid, M, 1u << t);
+            __syncthreads();
+            close = misc[0] > a.cap && t > pass_start;
+        }
+        if (!close) continue;
+        const uint32_t range = ((1u << t) - 1u) & ~((1u << pass_start) - 1u);
+        const uint32_t n = t3_emit(tab, misc, range, out + out_pos, tid);
+        if (tid == 0) {
+            hdr[1 + 3 * n_passes] = (uint32_t)pass_start | ((uint32_t)t << 8);
+            hdr[2 + 3 * n_passes] = out_pos;
+            hdr[3 + 3 * n_passes] = n;
+        }
+        ++n_passes;
+        out_pos += n;
+        if (t == T) break;
+        __syncthreads();
+        t3_clear(tab, misc, tid);
+        __syncthreads();
+        pass_start = t;
+        --t;                                     // path t again, alone in a fresh table
+    }
+    if (tid == 0) hdr[0] = (uint32_t)n_passes;
+}
+
+struct Scan3Args {
+    Items items;
+    const uint32_t *item_key;    // [n_items * 64] content-table index of every lane's alignment (KEY_EMPTY: padding)
+    // npairs[.. * 64 + lane] = node of step 2j | node of step 2j+1 << 16 of the lane's alignment
+    // (the last step twice when M is odd; 0 on padding lanes): what the filter reads
+    const uint32_t *npairs;
+    const uint16_t *images;
+    ImageLayout L;
+    const uint32_t *tile_masks;
+    const uint32_t *hdr;
+    const uint2 *list;
+    uint32_t stride;
+    int n_paths, tile, n_tiles, tile0, filter, debug;
+    const LenSeg *segs;          // this launch's segments (<= MAX_SEGS): seg0 .. seg0 + n_segs of n_segs_total
+    int n_segs, seg0, n_segs_total;
+    unsigned long long chunk_mult, chunk_inv_min;
+    uint32_t h_slots;            // table slots of a workgroup (power of two)
+    uint32_t *counts;
+    unsigned long long *worklist;
+    unsigned long long *wl_count;
+    uint32_t wl_capacity;
+    uint32_t *wl_hist;
+    uint32_t *status;
+};
+
+struct Tile3 {
+    const uint32_t *nodemask;    // LDS (or, NMG, the tile's masks in HBM)
+    const uint2 *table;          // LDS {key, mask}
+    uint32_t h_mask;
+    int tile_paths, path0;
+    int hdr_n;                   // lane p: length of tile path p
+    uint32_t hdr_a0;             // lane p: first step of tile path p
+    bool uniform_a0;
+    uint32_t sub_mask, gt_mask;
+};
+
+// Per-lane counters of one pass.  Nearly every alignment that passes the filter is good
+// for ALL paths of the pass or bad for all of them (tile paths are prefixes / siblings
+// of one another): two plain counters.  The rest ("mixed") goes into bit-sliced
+// counters: plane k holds bit k of 31 per-path counts.
+struct Counts3 {
+    uint32_t good = 0, bad = 0;          // lane p: totals of tile path p
+    uint32_t fg = 0, fb = 0;             // this lane's alignments good / bad for every path of the pass
+    uint32_t gp[6] = {}, bp[6] = {};
+    int n = 0;
+    __device__ __forceinline__ void add(uint32_t good_mask, uint32_t bad_mask, uint32_t sub, uint32_t)
+    {
+        const bool isg = good_mask == sub, isb = bad_mask == sub;
+        fg += isg ? 1u : 0u;
+        fb += isb ? 1u : 0u;
+        const bool mixed = !isg && !isb && (good_mask | bad_mask) != 0u;
+        if (WAVE_ANY(mixed)) {
+            uint32_t cg = mixed ? good_mask : 0u, cb = mixed ? bad_mask : 0u;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const uint32_t tg = gp[k] & cg, tb = bp[k] & cb;
+                gp[k] ^= cg;
+                bp[k] ^= cb;
+                cg = tg;
+                cb = tb;
+            }
+            if (++n == 63) flush_planes();
+        }
+    }
+    __device__ __forceinline__ void flush_planes()
+    {
+        const int lane = threadIdx.x & (WAVE - 1);
+        for (int p = 0; p < T3_MAX; p += 2) {       // two paths per reduction (sums < 64 * 64)
+            uint32_t vg = 0, vb = 0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                vg |= (((gp[k] >> p) & 1u) << k) | (((gp[k] >> (p + 1)) & 1u) << (16 + k));
+                vb |= (((bp[k] >> p) & 1u) << k) | (((bp[k] >> (p + 1)) & 1u) << (16 + k));
+            }
+            vg = wave_sum_u32(vg);
+            vb = wave_sum_u32(vb);
+            if (lane == p) {
+                good += vg & 0xFFFFu;
+                bad += vb & 0xFFFFu;
+            }
+            if (lane == p + 1) {
+                good += vg >> 16;
+                bad += vb >> 16;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) gp[k] = bp[k] = 0;
+        n = 0;
+    }
+    __device__ __forceinline__ void finish(uint32_t sub)
+    {
+        const int lane = threadIdx.x & (WAVE - 1);
+        if (WAVE_ANY(n != 0)) flush_planes();
+        const uint32_t sg = wave_sum_u32(fg), sb = wave_sum_u32(fb);
+        if ((sub >> lane) & 1u) {
+            good += sg;
+            bad += sb;
+        }
+        fg = fb = 0;
+    }
+};
+
+// dedup scorers: a lane stands for w identical alignments
+struct Counts3W {
+    uint32_t good = 0, bad = 0, fg = 0, fb = 0;
+    __device__ __forceinline__ void add(uint32_t good_mask, uint32_t bad_mask, uint32_t sub, uint32_t w)
+    {
+        const bool isg = good_mask == sub, isb = bad_mask == sub;
+        fg += isg ? w : 0u;
+        fb += isb ? w : 0u;
+        const bool mixed = !isg && !isb && (good_mask | bad_mask) != 0u;
+        if (WAVE_ANY(mixed)) {
+            const int lane = threadIdx.x & (WAVE - 1);
+            const uint32_t cg = mixed ? good_mask : 0u, cb = mixed ? bad_mask : 0u;
+            uint32_t any = cg | cb;
+#pragma unroll
+            for (int o = 1; o < WAVE; o <<= 1) any |= (uint32_t)__shfl_xor((int)any, o, WAVE);
+            any = (uint32_t)__builtin_amdgcn_readfirstlane((int)any);
+            while (any) {
+                const int p = __builtin_ctz(any);
+                any &= any - 1u;
+                const uint32_t sg = wave_sum_u32(((cg >> p) & 1u) ? w : 0u);
+                const uint32_t sb = wave_sum_u32(((cb >> p) & 1u) ? w : 0u);
+                if (lane == p) {
+                    good += sg;
+                    bad += sb;
+                }
+            }
+        }
+    }
+    __device__ __forceinline__ void finish(uint32_t sub)
+    {
+        const int lane = threadIdx.x & (WAVE - 1);
+        const uint32_t sg = wave_sum_u32(fg), sb = wave_sum_u32(fb);
+        if ((sub >> lane) & 1u) {
+            good += sg;
+            bad += sb;
+        }
+        fg = fb = 0;
+    }
+};
+
+template <int P0>
+struct Item3Regs {
+    uint32_t np[P0 > 0 ? P0 : 1];
+    uint32_t key, w;
+    uint32_t it;                 // (uniform) the item
+};
+
+// One item against the tile: the decided part.  pm: AND of the node masks of the lane's
+// alignment (bits 0..30: every node is on tile path p; bit 31: none is the tile's first node).
+template <bool W, typename Counts>
+__device__ __forceinline__ void scan3_decide(const Scan3Args &a, const Tile3 &tv, const LenSeg &sg,
+                                             uint32_t key, uint32_t w, uint32_t it, uint32_t pm,
+                                             uint2 e, uint32_t slot, int lane, Counts &wc)
+{
+    const int M = (int)sg.m;
+    const bool valid = key != KEY_EMPTY;
+    uint32_t pass = a.filter ? (pm & 0x7FFFFFFFu) : 0x7FFFFFFFu;
+    pass = valid ? (pass & tv.sub_mask) : 0u;
+    const bool has_a0 = !tv.uniform_a0 || (pm & NOT_A0) == 0u;
+    const uint32_t gt = pass & tv.gt_mask;          // src/alignments.cpp:500: m > n -> good
+    const uint32_t todo = pass & ~tv.gt_mask;
+    // ---- which of the tile's paths contain exactly this step sequence ----
+    const bool searching = todo != 0u;
+    while (true) {
+        const bool stop = !searching || e.x == key || e.x == KEY_EMPTY;
+        if (!WAVE_ANY(!stop)) break;
+        slot = stop ? slot : ((slot + 1u) & tv.h_mask);
+        const uint2 e2 = tv.table[slot];
+        e.x = stop ? e.x : e2.x;
+        e.y = stop ? e.y : e2.y;
+    }
+    const uint32_t fmask = (searching && e.x == key) ? (e.y & todo) : 0u;
+    const uint32_t good_mask = gt | fmask;
+    const uint32_t open = todo & ~fmask;
+    uint32_t bad_mask = open;
+    // ---- start-overhang triage (as in k_scan2; rare: the alignment must touch the tile's
+    // first node): survivors go to the exact DP ----
+    if (WAVE_ANY(open != 0u && has_a0)) {
+        uint32_t cfw = 0, crc = 0;
+        const uint16_t *bp = a.items.steps +
+                             ((size_t)sg.step_base + (size_t)(it - sg.item_lo) * (uint32_t)M) * WAVE + lane;
+        uint32_t want = (open != 0u && has_a0) ? open : 0u;
+#pragma unroll
+        for (int o = 1; o < WAVE; o <<= 1) want |= (uint32_t)__shfl_xor((int)want, o, WAVE);
+        want = (uint32_t)__builtin_amdgcn_readfirstlane((int)want);
+        while (want) {
+            const int p = __builtin_ctz(want);
+            want &= want - 1u;
+            const bool mine = ((open >> p) & 1u) != 0u && has_a0;
+            const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)tv.hdr_a0, p);
+            const uint32_t *pstep32 = reinterpret_cast<const uint32_t *>(
+                a.images + (size_t)(tv.path0 + p) * a.L.total + a.L.step_at());
+            bool cand_fw = false, cand_rc = false;
+            for (int t = 0; t < M; ++t) {
+                const uint32_t bt = bp[t * WAVE];
+                const bool live_fw = mine && t >= 1 && bt == a0;
+                if (WAVE_ANY(live_fw)) cand_fw |= tail_equals(bp, t, 1, M - t, 0u, pstep32, live_fw);
+                const bool live_rc = mine && t < M - 1 && (bt ^ 1u) == a0;
+                if (WAVE_ANY(live_rc)) cand_rc |= tail_equals(bp, t, -1, t + 1, 1u, pstep32, live_rc);
+            }
+            cfw |= cand_fw ? (1u << p) : 0u;
+            crc |= cand_rc ? (1u << p) : 0u;
+        }
+        bad_mask &= ~(cfw | crc);
+        push_item_pairs(a.worklist, a.wl_count, a.wl_capacity, a.wl_hist, a.status, a.n_paths, cfw, crc,
+                        lane, (uint32_t)tv.path0, tv.tile_paths, it * WAVE + (uint32_t)lane, M);
+    }
+    wc.add(good_mask, bad_mask, tv.sub_mask, w);
+}
+
+template <int P0, bool W, bool NMG, typename Counts>
+__device__ __forceinline__ void scan3_item(const Scan3Args &a, const Tile3 &tv, const LenSeg &sg,
+                                           const Item3Regs<P0> &r, int lane, Counts &wc)
+{
+    // the first probe goes out together with the node-mask reads
+    const uint32_t slot = r.key & tv.h_mask;
+    const uint2 e = tv.table[slot];
+    uint32_t pm = 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 0; k < P0; ++k) {
+        pm &= tv.nodemask[r.np[k] & 0xFFFFu];
+        pm &= tv.nodemask[r.np[k] >> 16];
+    }
+    scan3_decide<W>(a, tv, sg, r.key, r.w, r.it, pm, e, slot, lane, wc);
+}
+
+// The wave's items of one segment chunk, 64 at a time: one ballot drops the items none
+// of whose lanes can pass the filter.  P0 = ceil(M / 2) pair dwords per lane in registers
+// (two sets, loaded one item ahead), or 0: any length, loaded where it is used.
+template <int P0, bool W, bool NMG, typename Counts>
+__device__ __forceinline__ void scan3_items(const Scan3Args &a, const Tile3 &tv, const LenSeg &sg,
+                                            int chunk, int wave, int lane, Counts &wc)
+{
+    const int n_chunks = (int)sg.n_chunks;
+    const int item_stride = SCAN2_WAVES * n_chunks;
+    const int P0rt = ((int)sg.m + 1) / 2;
+    const uint32_t ulane = (uint32_t)lane;
+    for (int it0 = (int)sg.item_lo + chunk + wave * n_chunks; it0 < (int)sg.item_hi;
+         it0 += WAVE * item_stride) {
+        const int my_it = it0 + lane * item_stride;
+        const bool mine = my_it < (int)sg.item_hi;
+        bool keep = mine;
+        if (a.filter && mine) {
+            const uint32_t common = a.items.common[my_it];
+            if (common != NO_COMMON_NODE) {
+                const uint32_t m1 = tv.nodemask[common & 0x7FFFu], m2 = tv.nodemask[common >> 16];
+                keep = (((common & COMMON_EITHER) ? (m1 | m2) : (m1 & m2)) & tv.sub_mask) != 0u;
+            }
+        }
+        lanemask todo = WAVE_MASK(keep);
+        if (todo == 0) continue;
+        if constexpr (P0 > 0) {
+            auto load_item = [&](int src_in, Item3Regs<P0> &r) {
+                const int src = __builtin_amdgcn_readfirstlane(src_in);
+                const uint32_t it = (uint32_t)(it0 + src * item_stride);
+                r.it = it;
+                r.key = sgpr_ptr(a.item_key + (size_t)it * WAVE)[ulane];
+                r.w = W ? sgpr_ptr(a.items.weight + (size_t)it * WAVE)[ulane] : 1u;
+                const GLOBAL_AS uint32_t *pp =
+                    sgpr_ptr(a.npairs + ((size_t)sg.p0_base + (size_t)(it - sg.item_lo) * P0) * WAVE) + ulane;
+#pragma unroll
+                for (int k = 0; k < P0; ++k) r.np[k] = pp[k * WAVE];
+            };
+            Item3Regs<P0> ra, rb;
+            load_item(__builtin_ctzll(todo), ra);
+            while (true) {
+                lanemask rest = todo & (todo - 1);
+                load_item(__builtin_ctzll(rest ? rest : todo), rb);
+                scan3_item<P0, W, NMG>(a, tv, sg, ra, lane, wc);
+                if (rest == 0) break;
+                todo = rest;
+                rest = todo & (todo - 1);
+                load_item(__builtin_ctzll(rest ? rest : todo), ra);
+                scan3_item<P0, W, NMG>(a, tv, sg, rb, lane, wc);
+                if (rest == 0) break;
+                todo = rest;
+            }
+        } else {      // the longer alignments are rare: no second register set for them
+            for (; todo != 0; todo &= todo - 1) {
+                const int src = __builtin_amdgcn_readfirstlane(__builtin_ctzll(todo));
+                const uint32_t it = (uint32_t)(it0 + src * item_stride);
+                const uint32_t key = a.item_key[(size_t)it * WAVE + ulane];
+                const uint32_t w = W ? a.items.weight[(size_t)it * WAVE + ulane] : 1u;
+                const uint32_t slot = key & tv.h_mask;
+                const uint2 e = tv.table[slot];
+                const uint32_t *pp = a.npairs + ((size_t)sg.p0_base + (size_t)(it - sg.item_lo) * P0rt) * WAVE + ulane;
+                uint32_t pm = 0xFFFFFFFFu;
+                for (int k = 0; k < P0rt; ++k) {
+                    const uint32_t x = pp[(size_t)k * WAVE];
+                    pm &= tv.nodemask[x & 0xFFFFu];
+                    pm &= tv.nodemask[x >> 16];
+                }
+                scan3_decide<W>(a, tv, sg, key, w, it, pm, e, slot, lane, wc);
+            }
+        }
+    }
+}
+
+constexpr int SCAN3_REG_P0 = 6;      // alignments of up to 12 steps: node pairs in registers
+
+template <bool W, bool NMG>
+__global__ __launch_bounds__(SCAN2_THREADS, SCAN2_WAVES_PER_SIMD) void k_scan3(Scan3Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds32[];
+    const int tid = threadIdx.x;
+    const int lane = tid & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile_rel = blockIdx.x % a.n_tiles;
+    // (segment, chunk) <- the workgroup's row, as in k_scan2
+    LenSeg sg;
+    int chunk, seg;
+    {
+        const int y = blockIdx.x / a.n_tiles;
+        LenSeg mine{0u, 0u, 0u, 0u, 0u, 0u};
+        if (lane < a.n_segs) mine = a.segs[lane];
+        const uint32_t c = lane < a.n_segs
+                               ? seg_chunks(mine.item_hi - mine.item_lo, a.chunk_mult, a.chunk_inv_min)
+                               : 0u;
+        uint32_t incl = c;
+#pragma unroll
+        for (int o = 1; o < WAVE; o <<= 1) {
+            const uint32_t v = (uint32_t)__shfl_up((int)incl, o, WAVE);
+            if (lane >= o) incl += v;
+        }
+        const lanemask beyond = WAVE_MASK(incl > (uint32_t)y);
+        seg = beyond ? __builtin_ctzll(beyond) : 0;
+        sg.item_lo = (uint32_t)__builtin_amdgcn_readlane((int)mine.item_lo, seg);
+        sg.item_hi = (uint32_t)__builtin_amdgcn_readlane((int)mine.item_hi, seg);
+        sg.m = (uint32_t)__builtin_amdgcn_readlane((int)mine.m, seg);
+        sg.n_chunks = (uint32_t)__builtin_amdgcn_readlane((int)c, seg);
+        sg.step_base = (uint32_t)__builtin_amdgcn_readlane((int)mine.step_base, seg);
+        sg.p0_base = (uint32_t)__builtin_amdgcn_readlane((int)mine.p0_base, seg);
+        chunk = y - (int)__builtin_amdgcn_readlane((int)(incl - c), seg);
+    }
+    const int M = (int)sg.m;
+    const int v2 = a.L.v2;
+    Tile3 tv;
+    tv.path0 = (a.tile0 + tile_rel) * a.tile;
+    tv.tile_paths = min(a.tile, a.n_paths - tv.path0);
+    tv.h_mask = a.h_slots - 1u;
+    // LDS: node masks first (address = node * 4: no base to add), then the table
+    uint32_t *nodemask = lds32;
+    uint32_t *tab = lds32 + (NMG ? 0 : v2);
+    uint32_t *misc = tab + 2 * a.h_slots;
+    const uint32_t *gmask = a.tile_masks + (size_t)tile_rel * v2;
+    tv.nodemask = NMG ? gmask : nodemask;
+    tv.table = reinterpret_cast<const uint2 *>(tab);
+    if constexpr (!NMG) {
+        // straight from global memory into LDS (lane l of a wave-instruction lands at its
+        // uniform LDS base + 4 l)
+        for (int o = wave * WAVE; o < v2; o += SCAN2_THREADS)
+            if (o + lane < v2)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void *)(gmask + o + lane),
+                    (__attribute__((address_space(3))) void *)(nodemask + o), 4, 0, 0);
+    }
+    tv.hdr_n = 0;
+    tv.hdr_a0 = STEP_NOMATCH;
+    if (lane < tv.tile_paths) {
+        const uint16_t *img = a.images + (size_t)(tv.path0 + lane) * a.L.total;
+        tv.hdr_n = img[a.L.len_at()];
+        tv.hdr_a0 = img[a.L.step_at()];
+    }
+    const uint32_t tile_a0 = (uint32_t)__builtin_amdgcn_readlane((int)tv.hdr_a0, 0);
+    tv.uniform_a0 = WAVE_MASK(lane < tv.tile_paths && tv.hdr_a0 != tile_a0) == 0ull;
+    const uint32_t *hdr = a.hdr + ((size_t)tile_rel * a.n_segs_total + a.seg0 + seg) * T3_HDR_WORDS;
+    const uint2 *list = a.list + ((size_t)tile_rel * a.n_segs_total + a.seg0 + seg) * a.stride;
+    const int n_passes = (int)hdr[0];
+
+    uint32_t cnt_good = 0, cnt_bad = 0;      // lane p: totals of tile path p over all passes
+    for (int ps = 0; ps < n_passes; ++ps) {
+        const uint32_t tt = hdr[1 + 3 * ps], begin = hdr[2 + 3 * ps], count = hdr[3 + 3 * ps];
+        const int t0 = (int)(tt & 0xFFu), t1 = (int)(tt >> 8);
+        __syncthreads();                     // (the previous pass's probes are done)
+        {
+            uint4 *t4 = reinterpret_cast<uint4 *>(tab);
+            for (uint32_t i = tid; i < a.h_slots / 2; i += SCAN2_THREADS)
+                t4[i] = make_uint4(KEY_EMPTY, 0u, KEY_EMPTY, 0u);
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < count; i += SCAN2_THREADS) {
+            const uint2 en = list[begin + i];
+            uint32_t slot = en.x & tv.h_mask;
+            while (atomicCAS(&tab[2u * slot], KEY_EMPTY, en.x) != KEY_EMPTY) slot = (slot + 1u) & tv.h_mask;
+            tab[2u * slot + 1u] = en.y;
+        }
+        tv.sub_mask = ((1u << t1) - 1u) & ~((1u << t0) - 1u);
+        tv.gt_mask = 0;
+        for (int t = t0; t < t1; ++t)
+            if (__builtin_amdgcn_readlane(tv.hdr_n, t) < M) tv.gt_mask |= 1u << t;
+        if constexpr (!NMG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the node masks have landed
+        __syncthreads();
+        LenSeg sgl = sg;
+        if (a.debug == 1) sgl.item_hi = sgl.item_lo;      // timing probe: no items
+#define GFAL_RUN3(PP)                                                           \
+    do {                                                                        \
+        if constexpr (W) {                                                      \
+            Counts3W wc;                                                        \
+            scan3_items<PP, true, NMG>(a, tv, sgl, chunk, wave, lane, wc);      \
+            wc.finish(tv.sub_mask);                                             \
+            cnt_good += wc.good;                                                \
+            cnt_bad += wc.bad;                                                  \
+        } else {                                                                \
+            Counts3 wc;                                                         \
+            scan3_items<PP, false, NMG>(a, tv, sgl, chunk, wave, lane, wc);     \
+            wc.finish(tv.sub_mask);                                             \
+            cnt_good += wc.good;                                                \
+            cnt_bad += wc.bad;                                                  \
+        }                                                                       \
+    } while (0)
+        switch ((M + 1) / 2) {
+        case 1: GFAL_RUN3(1); break;
+        case 2: GFAL_RUN3(2); break;
+        case 3: GFAL_RUN3(3); break;
+        case 4: GFAL_RUN3(4); break;
+        case 5: GFAL_RUN3(5); break;
+        case 6: GFAL_RUN3(6); break;
+        default: GFAL_RUN3(0); break;
+        }
+#undef GFAL_RUN3
+    }
+    // workgroup reduction through LDS (the table is dead now), then one atomic per
+    // counter per workgroup
+    __syncthreads();
+    if (tid < 2 * MAX_TILE) misc[tid] = 0;
+    __syncthreads();
+    if (lane < tv.tile_paths) {
+        if (cnt_bad) atomicAdd(&misc[lane], cnt_bad);
+        if (cnt_good) atomicAdd(&misc[MAX_TILE + lane], cnt_good);
+    }
+    __syncthreads();
+    if (tid < tv.tile_paths) {
+        const uint32_t d = misc[tid], g = misc[MAX_TILE + tid];
+        if (d) atomicAdd(&a.counts[tv.path0 + tid], d);
+        if (g) atomicAdd(&a.counts[a.n_paths + tv.path0 + tid], g);
+    }
+}
 }  // namespace
 
 // --------------------------------------------------------------------------
@@ -3666,6 +4463,13 @@ struct gfal_scorer {
     uint32_t *d_item_weight = nullptr;   // Items::weight (dedup scorers)
     uint32_t *d_item_hash = nullptr;     // [n_items * 64] whash of every lane (k_scan2)
     uint32_t *d_item_pairs0 = nullptr;   // Scan2Args::pairs0
+    uint32_t *d_item_npairs = nullptr;   // Scan3Args::npairs
+    uint32_t *d_item_key = nullptr;      // Scan3Args::item_key (content-table index of every lane)
+    uint4 *d_ct_rec = nullptr;           // ContentTable::rec
+    // k_tile / k_scan3 per-call buffers: node masks per tile, window lists per (tile, length)
+    uint32_t *d_tile_masks = nullptr, *d_t3_hdr = nullptr;
+    uint2 *d_t3_list = nullptr;
+    size_t tile_masks_cap = 0, t3_hdr_cap = 0, t3_list_cap = 0;
     // k_scan2 takes the items of the well-populated alignment lengths: they come
     // first in the item order, one contiguous segment per length; the items of
     // the rare lengths follow and are scanned by k_scan
@@ -3799,6 +4603,7 @@ void free_scorer(gfal_scorer *s)
     (void)hipSetDevice(s->device);
     void *bufs[] = {s->d_item_pairs, s->d_item_pbase, s->d_item_common, s->d_item_hdr, s->d_item_weight,
                     s->d_item_hash, s->d_item_pairs0, s->d_lids, s->d_segs,
+                    s->d_item_npairs, s->d_item_key, s->d_ct_rec, s->d_tile_masks, s->d_t3_hdr, s->d_t3_list,
                     s->d_len_bins, s->d_order,
                     s->d_counts_slot,
                     s->d_node_local, s->d_node_hist, s->d_item_steps, s->d_item_base,
@@ -3904,10 +4709,19 @@ static const void *scan2_kernel(bool w, bool nm8, int grp)
     return reinterpret_cast<const void *>(table[w ? 1 : 0][nm8 ? 1 : 0][grp]);
 }
 
+static const void *scan3_kernel(bool w, bool nmg)
+{
+    typedef void (*kern_t)(Scan3Args);
+    static const kern_t table[2][2] = {{k_scan3<false, false>, k_scan3<false, true>},
+                                       {k_scan3<true, false>, k_scan3<true, true>}};
+    return reinterpret_cast<const void *>(table[w ? 1 : 0][nmg ? 1 : 0]);
+}
+
 static int create_impl(const int32_t *aln_off, const int32_t *aln_steps, int64_t n_aln,
                        int32_t n_nodes, int device, const int32_t *universe, int32_t n_universe,
                        int32_t shard_index, int32_t n_shards, bool dedup, gfal_scorer **out,
                        uint8_t *plan_owned = nullptr);
+static int build_content_table(gfal_scorer *s);
 
 int gfal_scorer_create_sharded(const int32_t *aln_off, const int32_t *aln_steps,
                                int64_t n_aln, int32_t n_nodes, int device,
@@ -4371,6 +5185,7 @@ static int create_impl(const int32_t *aln_off, const int32_t *aln_steps, int64_t
     std::vector<uint32_t> item_weight(dedup ? src.size() * WAVE : 0, 0u);
     std::vector<uint32_t> item_hash(src.size() * WAVE, 0u);
     std::vector<uint32_t> item_pairs0((size_t)n_pairs0, 0xFFFFFFFFu);
+    std::vector<uint32_t> item_npairs((size_t)n_pairs0, 0u);      // Scan3Args::npairs
     // where every item's pairs0 block starts (units of 64 dwords): its segment's base
     // plus its rank in the segment times ceil(m / 2)
     std::vector<uint32_t> item_p0base(src.size(), 0u);
@@ -4407,9 +5222,14 @@ static int create_impl(const int32_t *aln_off, const int32_t *aln_steps, int64_t
                             (uint32_t)px[2 * k + 1] |
                             ((2 * k + 2 < m) ? ((uint32_t)px[2 * k + 2] << 16) : 0u);
                     uint32_t *pairs0 = item_pairs0.data() + (size_t)item_p0base[it] * WAVE;
-                    for (int k = 0; k < (m + 1) / 2; ++k)
+                    uint32_t *npairs = item_npairs.data() + (size_t)item_p0base[it] * WAVE;
+                    for (int k = 0; k < (m + 1) / 2; ++k) {
                         pairs0[(size_t)k * WAVE + l] =
                             (uint32_t)px[2 * k] | ((2 * k + 1 < m) ? ((uint32_t)px[2 * k + 1] << 16) : 0xFFFF0000u);
+                        const uint32_t n_lo = (uint32_t)px[2 * k] >> 1;
+                        npairs[(size_t)k * WAVE + l] =
+                            n_lo | ((2 * k + 1 < m ? (uint32_t)px[2 * k + 1] >> 1 : n_lo) << 16);
+                    }
                     slot_orig[it * WAVE + (size_t)l] = is.idx[l];
                 }
                 // nodes every lane has: the first and the last such node of lane 0
@@ -4539,6 +5359,14 @@ static int create_impl(const int32_t *aln_off, const int32_t *aln_steps, int64_t
                                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET));
     CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_prep),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
+    for (int w = 0; w < 2; ++w)
+        for (int g = 0; g < 2; ++g)
+            CREATE_TRY(hipFuncSetAttribute(scan3_kernel(w != 0, g != 0),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET));
+    CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET));
+    CREATE_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tile_masks),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
     if ((rc = dev_upload(&s->d_node_local, node_local))) return fail(rc);
     if ((rc = dev_upload(&s->d_node_hist, hist))) return fail(rc);
     if ((rc = dev_upload(&s->d_item_steps, item_steps))) return fail(rc);
@@ -4550,6 +5378,7 @@ static int create_impl(const int32_t *aln_off, const int32_t *aln_steps, int64_t
     if (dedup && (rc = dev_upload(&s->d_item_weight, item_weight))) return fail(rc);
     if ((rc = dev_upload(&s->d_item_hash, item_hash))) return fail(rc);
     if ((rc = dev_upload(&s->d_item_pairs0, item_pairs0))) return fail(rc);
+    if ((rc = dev_upload(&s->d_item_npairs, item_npairs))) return fail(rc);
     if ((rc = dev_upload(&s->d_segs, segs))) return fail(rc);
     s->segs = segs;
     s->n_hash_items = n_hash_items;
@@ -4581,6 +5410,8 @@ static int create_impl(const int32_t *aln_off, const int32_t *aln_steps, int64_t
 
 #undef CREATE_TRY
     mark("device upload");
+    if ((rc = build_content_table(s))) return fail(rc);
+    mark("content table");
     guard.s = nullptr;
     *out = s;
     return GFAL_OK;
@@ -4693,6 +5524,135 @@ static int ensure_call_buffers(gfal_scorer *s, int32_t n_paths, const ImageLayou
         if (s->have_last) HIP_TRY(hipStreamSynchronize(s->last_stream));
         int rc = dev_reserve(&s->d_lids, &s->lids_cap, want);
         if (rc) return rc;
+    }
+    return GFAL_OK;
+}
+
+// k_tile_masks + k_tile + k_scan3 over the segments [0, n_segs) of the scorer, in slabs of
+// tiles that fit the window-list buffer.
+static int launch_scan3(gfal_scorer *s, hipStream_t st, const Items &items, const ImageLayout &L,
+                        int32_t n_paths, int32_t max_path_len, int filter, int n_segs, int n_items3,
+                        int want_groups, int slots, uint32_t *d_counts, unsigned long long *wl_count,
+                        uint32_t *d_hist)
+{
+    const int tile = std::max(1, std::min(T3_MAX, (int)n_paths));
+    const int n_tiles = (n_paths + tile - 1) / tile;
+    // LDS of a k_scan3 workgroup: node masks (4 bytes per node) + table (8 bytes per slot).
+    // The table holds at least one path's windows at load 1/2 (4096 slots); many nodes:
+    // the masks stay in HBM (read through L1 / L2)
+    const size_t mask_bytes = (size_t)L.v2 * sizeof(uint32_t);
+    uint32_t h_slots = 8192;
+    bool nmg = false;
+    if (mask_bytes + (size_t)h_slots * 8 + 256 > (size_t)LDS_BUDGET) h_slots = 4096;
+    if (mask_bytes + (size_t)h_slots * 8 + 256 > (size_t)LDS_BUDGET) {
+        nmg = true;
+        h_slots = 8192;
+    }
+    if (const char *env = getenv("GFAL_SCAN3_SLOTS")) {
+        const int v = atoi(env);
+        if (v == 4096 || v == 8192) h_slots = (uint32_t)v;
+    }
+    if (const char *env = getenv("GFAL_SCAN3_NMG")) nmg = atoi(env) != 0;
+    const size_t lds3 = (nmg ? 0 : mask_bytes) + (size_t)h_slots * 8 + 256;
+    if (lds3 > (size_t)LDS_BUDGET) {
+        nmg = true;
+    }
+    const uint32_t stride = (uint32_t)tile * 2u * (uint32_t)max_path_len;
+    // slabs of tiles: the window lists of a slab stay below GFAL_SCAN3_LIST_MB (worst case:
+    // every window of every path its own entry; what is touched is what exists)
+    size_t list_limit = (size_t)6 << 30;
+    if (const char *env = getenv("GFAL_SCAN3_LIST_MB")) list_limit = (size_t)std::max(1, atoi(env)) << 20;
+    const size_t per_tile = (size_t)n_segs * stride * sizeof(uint2);
+    const int slab_tiles = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_tiles, list_limit / std::max<size_t>(per_tile, 1)));
+    {
+        const size_t want_masks = (size_t)slab_tiles * L.v2, want_hdr = (size_t)slab_tiles * n_segs * T3_HDR_WORDS,
+                     want_list = (size_t)slab_tiles * n_segs * stride;
+        if (want_masks > s->tile_masks_cap || want_hdr > s->t3_hdr_cap || want_list > s->t3_list_cap) {
+            if (s->have_last) HIP_TRY(hipStreamSynchronize(s->last_stream));
+            int rc;
+            if ((rc = dev_reserve(&s->d_tile_masks, &s->tile_masks_cap, want_masks))) return rc;
+            if ((rc = dev_reserve(&s->d_t3_hdr, &s->t3_hdr_cap, want_hdr))) return rc;
+            if ((rc = dev_reserve(&s->d_t3_list, &s->t3_list_cap, want_list))) return rc;
+        }
+    }
+    TileArgs ta;
+    ta.items = items;
+    ta.ct = ContentTable{s->d_ct_rec, s->ct_mask};
+    ta.images = s->d_images;
+    ta.L = L;
+    ta.lids = s->d_lids;
+    ta.n_paths = n_paths;
+    ta.tile = tile;
+    ta.segs = s->d_segs;
+    ta.n_segs = n_segs;
+    ta.cap = h_slots / 2;
+    ta.tile_masks = s->d_tile_masks;
+    ta.hdr = s->d_t3_hdr;
+    ta.list = s->d_t3_list;
+    ta.stride = stride;
+
+    Scan3Args a3;
+    a3.items = items;
+    a3.item_key = s->d_item_key;
+    a3.npairs = s->d_item_npairs;
+    a3.images = s->d_images;
+    a3.L = L;
+    a3.tile_masks = s->d_tile_masks;
+    a3.hdr = s->d_t3_hdr;
+    a3.list = s->d_t3_list;
+    a3.stride = stride;
+    a3.n_paths = n_paths;
+    a3.tile = tile;
+    a3.filter = filter ? 1 : 0;
+    a3.debug = getenv("GFAL_DEBUG_SCAN2") ? atoi(getenv("GFAL_DEBUG_SCAN2")) : 0;
+    a3.n_segs_total = n_segs;
+    a3.h_slots = h_slots;
+    a3.counts = d_counts;
+    a3.worklist = s->d_worklist;
+    a3.wl_count = wl_count;
+    a3.wl_capacity = s->wl_capacity;
+    a3.wl_hist = d_hist;
+    a3.status = s->d_status;
+    // chunks per segment: in proportion to the segment's items (see k_scan2's launch)
+    int y_want = (want_groups + n_tiles - 1) / n_tiles;
+    int min_items = 24 * SCAN2_WAVES;
+    if (n_tiles < slots) {
+        int rounds4 = n_tiles <= 40 ? 4 : 8;
+        if (const char *env = getenv("GFAL_SCAN2_ROUNDS4")) rounds4 = std::max(1, atoi(env));
+        y_want = std::min(y_want, (rounds4 * slots / 4 + n_tiles - 1) / n_tiles);
+        min_items = 12 * SCAN2_WAVES;
+    }
+    if (const char *env = getenv("GFAL_SCAN3_MIN_ITEMS")) min_items = std::max(1, atoi(env)) * SCAN2_WAVES;
+    a3.chunk_mult = (((unsigned long long)y_want << 24) + (unsigned long long)n_items3 - 1) /
+                    (unsigned long long)std::max<int64_t>(n_items3, 1);
+    a3.chunk_inv_min = (1ull << 24) / (unsigned long long)min_items;
+
+    s->last_tile = tile;
+    s->last_lds = (int)lds3;
+    for (int t0 = 0; t0 < n_tiles; t0 += slab_tiles) {
+        const int nt = std::min(slab_tiles, n_tiles - t0);
+        ta.tile0 = t0;
+        hipLaunchKernelGGL(k_tile_masks, dim3((unsigned)nt), dim3(1024), mask_bytes, st, ta);
+        hipLaunchKernelGGL(k_tile, dim3((unsigned)nt, (unsigned)n_segs), dim3(1024), (size_t)T3_TILE_LDS, st, ta);
+        HIP_TRY(hipGetLastError());
+        a3.tile0 = t0;
+        a3.n_tiles = nt;
+        for (int s0 = 0; s0 < n_segs; s0 += MAX_SEGS) {
+            const int ns = std::min(MAX_SEGS, n_segs - s0);
+            a3.segs = s->d_segs + s0;
+            a3.n_segs = ns;
+            a3.seg0 = s0;
+            unsigned y_total = 0;
+            for (int k = 0; k < ns; ++k) {
+                const LenSeg &sg = s->segs[(size_t)(s0 + k)];
+                y_total += seg_chunks(sg.item_hi - sg.item_lo, a3.chunk_mult, a3.chunk_inv_min);
+            }
+            const unsigned grid3 = (unsigned)nt * y_total;
+            void *kargs[] = {&a3};
+            HIP_TRY(hipLaunchKernel(scan3_kernel(s->d_item_weight != nullptr, nmg), dim3(grid3),
+                                    dim3(SCAN2_THREADS), kargs, lds3, st));
+            s->last_grid += (int)grid3;
+        }
     }
     return GFAL_OK;
 }
@@ -4838,7 +5798,7 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
         // is ahead (scripts/small_batch_probe.py)
         if (n_paths < 96) n_segs2 = 0;
         if (!hash_fits || s->scan_mode == 1) n_segs2 = 0;
-        if (!chain_fits || s->scan_mode == 2) n_segs2 = (int)s->segs.size();
+        if (!chain_fits || s->scan_mode == 2 || s->scan_mode == 3) n_segs2 = (int)s->segs.size();
         if (n_segs2 == 0 && !chain_fits) return GFAL_E_RANGE;
         const int item_lo_chain = n_segs2 > 0 ? (int)s->segs[(size_t)n_segs2 - 1].item_hi : 0;
         if (children) {
@@ -4884,7 +5844,15 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
         }
 
         int scan_forks = 0;          // side streams that run a scan launch of this call
-        if (n_segs2 > 0 && !children) {
+        // k_scan3 (content identities, 31 paths per tile) takes what k_scan2 took unless
+        // GFAL_SCAN=2 asks for the older kernel
+        const bool use3 = n_segs2 > 0 && !children && s->scan_mode != 2;
+        if (use3) {
+            const int rc3 = launch_scan3(s, st, items, L, n_paths, max_path_len, filter, n_segs2, item_lo_chain,
+                                         want_groups, slots, d_counts, wl_count, d_hist);
+            if (rc3) return rc3;
+        }
+        if (n_segs2 > 0 && !children && !use3) {
             Scan2Args a2;
             a2.items = items;
             a2.item_hash = s->d_item_hash;
@@ -5233,8 +6201,43 @@ static int score_stage(gfal_scorer *s, const int32_t *path_off, const int32_t *p
     return rc;
 }
 
-// The search-mode index of a scorer (inverted lists by node, content table),
-// built on the device from the resident items at the first use.
+// The content table of a scorer: one entry per distinct step sequence among the
+// resident alignments (open addressing on the content hash), and every lane's entry.
+// Built on the device when the scorer is created: k_tile looks the windows of the
+// candidate paths up in it, k_scan3 compares entry indices, k_child reads multiplicities.
+static int build_content_table(gfal_scorer *s)
+{
+    HIP_TRY(hipSetDevice(s->device));
+    const uint32_t n_slots = (uint32_t)s->n_items * WAVE;
+    uint32_t slots_pow2 = 1024;
+    while ((uint64_t)slots_pow2 < 2ull * std::max<uint32_t>(n_slots, 1u)) slots_pow2 <<= 1;
+    s->ct_mask = slots_pow2 - 1u;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_ct_key), (size_t)slots_pow2 * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_ct_hash), (size_t)slots_pow2 * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_ct_mult), (size_t)slots_pow2 * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_ct_rec), (size_t)slots_pow2 * sizeof(uint4)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_item_key), std::max<size_t>(n_slots, 1) * sizeof(uint32_t)));
+    hipStream_t st = s->stream;
+    HIP_TRY(hipMemsetAsync(s->d_ct_key, 0xFF, (size_t)slots_pow2 * sizeof(uint32_t), st));
+    HIP_TRY(hipMemsetAsync(s->d_ct_hash, 0, (size_t)slots_pow2 * sizeof(uint32_t), st));
+    HIP_TRY(hipMemsetAsync(s->d_ct_mult, 0, (size_t)slots_pow2 * sizeof(uint32_t), st));
+    HIP_TRY(hipMemsetAsync(s->d_ct_rec, 0xFF, (size_t)slots_pow2 * sizeof(uint4), st));
+    HIP_TRY(hipMemsetAsync(s->d_item_key, 0xFF, std::max<size_t>(n_slots, 1) * sizeof(uint32_t), st));
+    if (n_slots > 0) {
+        const Items items{s->d_item_steps, s->d_item_base, s->d_item_len, s->d_item_pairs,
+                          s->d_item_pbase, s->n_items, s->d_item_common, s->d_item_hdr, s->d_item_weight};
+        const unsigned blocks = (n_slots + 255u) / 256u;
+        hipLaunchKernelGGL(k_ct_build, dim3(blocks), dim3(256), 0, st, items, s->d_slot_orig, n_slots,
+                           s->d_item_hash, s->d_ct_key, s->d_ct_hash, s->d_ct_mult, s->ct_mask, s->d_ct_rec,
+                           s->d_item_key);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    return GFAL_OK;
+}
+
+// The search-mode index of a scorer (inverted lists by node), built on the device
+// from the resident items at the first use.
 static int build_child_index(gfal_scorer *s)
 {
     if (s->child_index) return GFAL_OK;
@@ -5255,18 +6258,9 @@ static int build_child_index(gfal_scorer *s)
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_inv_off), (size_t)(n_loc + 1) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_inv_ent),
                       std::max<size_t>((size_t)s->n_item_u16, 1) * sizeof(uint4)));
-    uint32_t slots_pow2 = 1024;
-    while ((uint64_t)slots_pow2 < 2ull * std::max<uint32_t>(n_slots, 1u)) slots_pow2 <<= 1;
-    s->ct_mask = slots_pow2 - 1u;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_ct_key), (size_t)slots_pow2 * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_ct_hash), (size_t)slots_pow2 * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_ct_mult), (size_t)slots_pow2 * sizeof(uint32_t)));
     hipStream_t st = s->stream;
     HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)(n_loc + 1) * sizeof(uint32_t), st));
     HIP_TRY(hipMemsetAsync(s->d_inv_off, 0, (size_t)(n_loc + 1) * sizeof(uint32_t), st));
-    HIP_TRY(hipMemsetAsync(s->d_ct_key, 0xFF, (size_t)slots_pow2 * sizeof(uint32_t), st));
-    HIP_TRY(hipMemsetAsync(s->d_ct_hash, 0, (size_t)slots_pow2 * sizeof(uint32_t), st));
-    HIP_TRY(hipMemsetAsync(s->d_ct_mult, 0, (size_t)slots_pow2 * sizeof(uint32_t), st));
     if (n_slots > 0) {
         const Items items{s->d_item_steps, s->d_item_base, s->d_item_len, s->d_item_pairs,
                           s->d_item_pbase, s->n_items, s->d_item_common, s->d_item_hdr, s->d_item_weight};
@@ -5276,8 +6270,6 @@ static int build_child_index(gfal_scorer *s)
         hipLaunchKernelGGL(k_inv_scan, dim3(1), dim3(1024), 0, st, cnt, n_loc, s->d_inv_off, cursor);
         hipLaunchKernelGGL(k_inv_build, dim3(blocks), dim3(256), 0, st, items, s->d_slot_orig, n_slots, cursor,
                            s->d_inv_ent);
-        hipLaunchKernelGGL(k_ct_build, dim3(blocks), dim3(256), 0, st, items, s->d_slot_orig, n_slots,
-                           s->d_item_hash, s->d_ct_key, s->d_ct_hash, s->d_ct_mult, s->ct_mask);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipStreamSynchronize(st));
