@@ -3102,15 +3102,18 @@ __global__ __launch_bounds__(1024) void k_inv_scan(const uint32_t *__restrict__ 
 
 // one thread per lane: enter its alignment into the content table
 // rec[idx] = {representative lane, m | step 0 << 16, steps 1..2, steps 3..4}: what a lookup
-// compares in one 16-byte load (k_tile); lane_key[lane] = idx, the identity of the lane's
-// content (k_scan3)
+// compares in one 16-byte load (k_tile); idx, the identity of the lane's content, goes into
+// the lane's item record (k_scan3)
 __global__ void k_ct_build(Items items, const int32_t *__restrict__ slot_orig, uint32_t n_slots,
                            const uint32_t *__restrict__ item_hash, uint32_t *__restrict__ key,
                            uint32_t *__restrict__ hash, uint32_t *__restrict__ mult, uint32_t mask,
-                           uint4 *__restrict__ rec, uint32_t *__restrict__ lane_key)
+                           uint4 *__restrict__ rec, uint32_t *__restrict__ rec3,
+                           const uint32_t *__restrict__ item_r3)
 {
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= n_slots || slot_orig[slot] < 0) return;
+    // the lane's key: first dword of its item record (k_scan3)
+    uint32_t *my_key = rec3 + (size_t)item_r3[slot >> 6] * WAVE + (slot & 63u);
     const uint32_t h = item_hash[slot];
     const uint32_t w = items.weight ? items.weight[slot] : 1u;
     uint32_t idx = h & mask;
@@ -3124,12 +3127,12 @@ __global__ void k_ct_build(Items items, const int32_t *__restrict__ slot_orig, u
             const uint16_t *bp = items.steps + (size_t)items.base[it] * WAVE + (slot & 63u);
             auto st = [&](int k) -> uint32_t { return k < m ? (uint32_t)bp[(size_t)k * WAVE] : 0u; };
             rec[idx] = make_uint4(slot, (uint32_t)m | (st(0) << 16), st(1) | (st(2) << 16), st(3) | (st(4) << 16));
-            lane_key[slot] = idx;
+            *my_key = idx;
             return;
         }
         if (item_hash[prev] == h && lane_same_content(items, prev, slot)) {
             atomicAdd(&mult[idx], w);
-            lane_key[slot] = idx;
+            *my_key = idx;
             return;
         }
         idx = (idx + 1u) & mask;
@@ -3688,6 +3691,7 @@ constexpr int HT_LOG = 13;
 constexpr int HT_SLOTS = 1 << HT_LOG;      // k_tile's own table (dedup of the tile's windows)
 constexpr uint32_t KEY_EMPTY = 0xFFFFFFFFu;
 constexpr int T3_HDR_WORDS = 96;           // per (tile, length): n_passes, then {t0 | t1 << 8, begin, count} per pass
+constexpr int T3_THDR_WORDS = 128;         // per tile: 32 lengths | 32 first steps | 32 common prefixes with path 0
 constexpr int T3_CT_INLINE = 5;            // steps of an alignment a content-table record carries
 
 struct ContentTable {
@@ -3705,24 +3709,68 @@ struct TileArgs {
     const LenSeg *segs;
     int n_segs;
     uint32_t cap;                  // entries one k_scan3 pass holds (half its table)
-    uint32_t *tile_masks;          // [tiles of the slab][v2]
+    int filter, v2p;               // v2p: mask words per tile = v2 + 2 (word v2 stays zero: padding lanes point at it)
+    uint32_t *tile_hdr;            // [tiles of the slab][T3_THDR_WORDS]
+    uint32_t *tile_masks;          // [tiles of the slab][v2p]
     uint32_t *hdr;                 // [tiles of the slab][n_segs][T3_HDR_WORDS]
     uint2 *list;                   // [tiles of the slab][n_segs][stride]
     uint32_t stride;
 };
 
 // which tile paths carry each node (the filter of src/eval.cpp:81-91 as a bit test);
-// bit 31 (NOT_A0) on every node but the one of the tile's first step
-__global__ __launch_bounds__(1024) void k_tile_masks(TileArgs a)
+// bit 31 (NOT_A0) on every node but the one of the tile's first step.  What k_scan3 would
+// otherwise test per item is folded into the masks: without the filter every node counts
+// as being on every path; tile paths that do not start with the same step: no node keeps
+// NOT_A0 (every open pair takes the overhang test).  Also the tile's header (lengths,
+// first steps) and -- block 0 -- the cold arguments of k_scan3.
+struct Scan3Cold;
+__global__ __launch_bounds__(1024) void k_tile_masks(TileArgs a, const Scan3Cold *cold_src, Scan3Cold *cold_dst,
+                                                     int cold_bytes)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds32[];
     const int tid = threadIdx.x;
+    if (blockIdx.x == 0 && cold_dst)
+        for (int i = tid; i < cold_bytes / 4; i += 1024)
+            reinterpret_cast<uint32_t *>(cold_dst)[i] = reinterpret_cast<const uint32_t *>(cold_src)[i];
     const int tile = a.tile0 + (int)blockIdx.x;
     const int path0 = tile * a.tile;
     const int T = min(a.tile, a.n_paths - path0);
     const int v2 = a.L.v2, nm = a.L.nm;
-    for (int v = tid; v < v2; v += 1024) lds32[v] = NOT_A0;
+    const uint32_t init = a.filter ? NOT_A0 : 0xFFFFFFFFu;
+    for (int v = tid; v < v2; v += 1024) lds32[v] = init;
+    if (tid < WAVE) {
+        uint32_t n = 0, a0 = STEP_NOMATCH;
+        if (tid < T) {
+            const uint16_t *img = a.images + (size_t)(path0 + tid) * a.L.total;
+            n = img[a.L.len_at()];
+            a0 = img[a.L.step_at()];
+        }
+        const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)a0, 0);
+        const bool uniform = WAVE_MASK(tid < T && a0 != first) == 0ull;
+        if (tid < 32) {
+            a.tile_hdr[(size_t)blockIdx.x * T3_THDR_WORDS + tid] = n;
+            a.tile_hdr[(size_t)blockIdx.x * T3_THDR_WORDS + 32 + tid] = a0;
+        }
+        if (tid == 0) {
+            lds32[v2] = uniform ? 1u : 0u;
+            lds32[v2 + 1] = first;
+        }
+    }
     __syncthreads();
+    // how many of its first 64 steps every path shares with the tile's first path
+    // (k_scan3's overhang test looks at M - 1 leading steps)
+    for (int t = tid >> 6; t < T; t += 1024 / WAVE) {
+        const int l = tid & (WAVE - 1);
+        const uint32_t *p0 = reinterpret_cast<const uint32_t *>(a.images + (size_t)path0 * a.L.total + a.L.step_at());
+        const uint32_t *pt = reinterpret_cast<const uint32_t *>(a.images + (size_t)(path0 + t) * a.L.total + a.L.step_at());
+        uint32_t x = 0;
+        if (l < 32 && l < nm / 2) x = p0[l] ^ pt[l];
+        const lanemask lo = WAVE_MASK((x & 0xFFFFu) != 0u), hi = WAVE_MASK((x >> 16) != 0u);
+        int lcp = 64;
+        if (lo) lcp = min(lcp, 2 * __builtin_ctzll(lo));
+        if (hi) lcp = min(lcp, 2 * __builtin_ctzll(hi) + 1);
+        if (l == 0) a.tile_hdr[(size_t)blockIdx.x * T3_THDR_WORDS + 64 + t] = (uint32_t)lcp;
+    }
     for (int t = 0; t < T; ++t) {
         const uint32_t *lsrc = reinterpret_cast<const uint32_t *>(a.lids + (size_t)(path0 + t) * nm);
         for (int o = tid; o < nm / 2; o += 1024) {
@@ -3733,13 +3781,15 @@ __global__ __launch_bounds__(1024) void k_tile_masks(TileArgs a)
         }
     }
     __syncthreads();
-    if (tid == 0) {
-        const uint32_t a0 = a.images[(size_t)path0 * a.L.total + a.L.step_at()];
-        if (a0 < STEP_NOMATCH) lds32[a0 >> 1] &= ~NOT_A0;
+    const bool uniform = lds32[v2] != 0u;
+    const uint32_t a0 = lds32[v2 + 1];
+    uint32_t *dst = a.tile_masks + (size_t)blockIdx.x * a.v2p;
+    for (int v = tid; v < v2; v += 1024) {
+        uint32_t m = lds32[v];
+        if (!uniform || (a0 < STEP_NOMATCH && (uint32_t)v == (a0 >> 1))) m &= ~NOT_A0;
+        dst[v] = m;
     }
-    __syncthreads();
-    uint32_t *dst = a.tile_masks + (size_t)blockIdx.x * v2;
-    for (int v = tid; v < v2; v += 1024) dst[v] = lds32[v];
+    if (tid < 2) dst[v2 + tid] = 0;
 }
 
 // index of the content  W[k] = F[dir * k] ^ flip  (k < M) in the content table, or
@@ -3995,24 +4045,13 @@ __global__ __launch_bounds__(1024, 8) void k_tile(TileArgs a)
     if (tid == 0) hdr[0] = (uint32_t)n_passes;
 }
 
-struct Scan3Args {
-    Items items;
-    const uint32_t *item_key;    // [n_items * 64] content-table index of every lane's alignment (KEY_EMPTY: padding)
-    // npairs[.. * 64 + lane] = node of step 2j | node of step 2j+1 << 16 of the lane's alignment
-    // (the last step twice when M is odd; 0 on padding lanes): what the filter reads
-    const uint32_t *npairs;
+// What only the rare paths of k_scan3 read (the overhang triage, the worklist): kept in
+// HBM behind one pointer, so that none of it occupies SGPRs across the item loop.
+struct Scan3Cold {
+    const uint16_t *item_steps;  // Items::steps
     const uint16_t *images;
     ImageLayout L;
-    const uint32_t *tile_masks;
-    const uint32_t *hdr;
-    const uint2 *list;
-    uint32_t stride;
-    int n_paths, tile, n_tiles, tile0, filter, debug;
-    const LenSeg *segs;          // this launch's segments (<= MAX_SEGS): seg0 .. seg0 + n_segs of n_segs_total
-    int n_segs, seg0, n_segs_total;
-    unsigned long long chunk_mult, chunk_inv_min;
-    uint32_t h_slots;            // table slots of a workgroup (power of two)
-    uint32_t *counts;
+    int n_paths;
     unsigned long long *worklist;
     unsigned long long *wl_count;
     uint32_t wl_capacity;
@@ -4020,116 +4059,134 @@ struct Scan3Args {
     uint32_t *status;
 };
 
+// One length segment as k_scan3 sees it.  Item `it` of the segment: its record at
+// rec3[(r3_base + (it - item_lo) * R) * 64], R = 1 + ceil(m / 2) (+ 1: dedup weights) dwords
+// per lane: the lane's content key, the byte offsets into the node masks of the nodes of
+// its steps two to a dword (the last step twice when m is odd; padding lanes: the offset
+// of the mask word that is always zero), the weight.
+struct Seg3 {
+    uint32_t item_lo, item_hi, m, n_chunks, step_base, r3_base;
+};
+
+struct Scan3Args {
+    const uint32_t *rec3;        // item records
+    const uint32_t *common;      // Items::common
+    const Scan3Cold *cold;
+    const uint32_t *tile_masks;  // [tiles of the slab][v2p] node masks; word v2p - 2 stays zero
+    const uint32_t *tile_hdr;    // [tiles of the slab][T3_THDR_WORDS]
+    const uint32_t *hdr;
+    const uint2 *list;
+    uint32_t stride;
+    int n_paths, tile, n_tiles, tile0, debug;
+    int v2p;                     // mask words per tile
+    int nm_shift;                // NMG: record offsets are node indices (2) or byte offsets (0)
+    const Seg3 *segs;            // this launch's segments (<= MAX_SEGS): seg0 .. seg0 + n_segs of n_segs_total
+    int n_segs, seg0, n_segs_total;
+    unsigned long long chunk_mult, chunk_inv_min;
+    uint32_t h_slots;            // table slots of a workgroup (power of two)
+    uint32_t *counts;
+};
+
+typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
+typedef __attribute__((address_space(3))) const unsigned long long lds_cu64;
+// table entry {key, mask} at an LDS byte address (one ds_read_b64)
+__device__ __forceinline__ uint2 lds_entry(uint32_t byte_addr)
+{
+    const unsigned long long v = *(lds_cu64 *)(uintptr_t)byte_addr;
+    return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+}
+
 struct Tile3 {
-    const uint32_t *nodemask;    // LDS (or, NMG, the tile's masks in HBM)
-    const uint2 *table;          // LDS {key, mask}
+    const char *gmask;           // NMG: the tile's node masks in HBM
+    int nm_shift;
+    uint32_t tab_base;           // LDS byte address of the table
     uint32_t h_mask;
+    uint32_t sub_mask, gt_mask, half;   // half: popcount(sub_mask) / 2
     int tile_paths, path0;
-    int hdr_n;                   // lane p: length of tile path p
-    uint32_t hdr_a0;             // lane p: first step of tile path p
-    bool uniform_a0;
-    uint32_t sub_mask, gt_mask;
 };
 
-// Per-lane counters of one pass.  Nearly every alignment that passes the filter is good
-// for ALL paths of the pass or bad for all of them (tile paths are prefixes / siblings
-// of one another): two plain counters.  The rest ("mixed") goes into bit-sliced
-// counters: plane k holds bit k of 31 per-path counts.
-struct Counts3 {
-    uint32_t good = 0, bad = 0;          // lane p: totals of tile path p
-    uint32_t fg = 0, fb = 0;             // this lane's alignments good / bad for every path of the pass
-    uint32_t gp[6] = {}, bp[6] = {};
-    int n = 0;
-    __device__ __forceinline__ void add(uint32_t good_mask, uint32_t bad_mask, uint32_t sub, uint32_t)
-    {
-        const bool isg = good_mask == sub, isb = bad_mask == sub;
-        fg += isg ? 1u : 0u;
-        fb += isb ? 1u : 0u;
-        const bool mixed = !isg && !isb && (good_mask | bad_mask) != 0u;
-        if (WAVE_ANY(mixed)) {
-            uint32_t cg = mixed ? good_mask : 0u, cb = mixed ? bad_mask : 0u;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                const uint32_t tg = gp[k] & cg, tb = bp[k] & cb;
-                gp[k] ^= cg;
-                bp[k] ^= cb;
-                cg = tg;
-                cb = tb;
-            }
-            if (++n == 63) flush_planes();
-        }
-    }
-    __device__ __forceinline__ void flush_planes()
-    {
-        const int lane = threadIdx.x & (WAVE - 1);
-        for (int p = 0; p < T3_MAX; p += 2) {       // two paths per reduction (sums < 64 * 64)
-            uint32_t vg = 0, vb = 0;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                vg |= (((gp[k] >> p) & 1u) << k) | (((gp[k] >> (p + 1)) & 1u) << (16 + k));
-                vb |= (((bp[k] >> p) & 1u) << k) | (((bp[k] >> (p + 1)) & 1u) << (16 + k));
-            }
-            vg = wave_sum_u32(vg);
-            vb = wave_sum_u32(vb);
-            if (lane == p) {
-                good += vg & 0xFFFFu;
-                bad += vb & 0xFFFFu;
-            }
-            if (lane == p + 1) {
-                good += vg >> 16;
-                bad += vb >> 16;
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 6; ++k) gp[k] = bp[k] = 0;
-        n = 0;
-    }
-    __device__ __forceinline__ void finish(uint32_t sub)
-    {
-        const int lane = threadIdx.x & (WAVE - 1);
-        if (WAVE_ANY(n != 0)) flush_planes();
-        const uint32_t sg = wave_sum_u32(fg), sb = wave_sum_u32(fb);
-        if ((sub >> lane) & 1u) {
-            good += sg;
-            bad += sb;
-        }
-        fg = fb = 0;
-    }
-};
+template <bool NMG>
+__device__ __forceinline__ uint32_t nm_read(const Tile3 &tv, uint32_t off)
+{
+    if constexpr (NMG) return *reinterpret_cast<const uint32_t *>(tv.gmask + ((size_t)off << tv.nm_shift));
+    else return *(lds_cu32 *)(uintptr_t)off;     // the node masks start at LDS address 0
+}
 
-// dedup scorers: a lane stands for w identical alignments
-struct Counts3W {
-    uint32_t good = 0, bad = 0, fg = 0, fb = 0;
-    __device__ __forceinline__ void add(uint32_t good_mask, uint32_t bad_mask, uint32_t sub, uint32_t w)
+// OR / sum over the wave, all in registers (DPP inside a row of 16, four readlanes across)
+__device__ __forceinline__ uint32_t wave_or_dpp(uint32_t v)
+{
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);     // quad_perm [1,0,3,2]
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);     // quad_perm [2,3,0,1]
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);    // row_half_mirror
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true);    // row_mirror
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) | (uint32_t)__builtin_amdgcn_readlane((int)v, 16) |
+           (uint32_t)__builtin_amdgcn_readlane((int)v, 32) | (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+}
+__device__ __forceinline__ uint32_t wave_add_dpp(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) + (uint32_t)__builtin_amdgcn_readlane((int)v, 16) +
+           (uint32_t)__builtin_amdgcn_readlane((int)v, 32) + (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+}
+
+// Counters of one pass.  Nearly every alignment that passes the filter is good for ALL
+// paths of the pass or bad for all of them (tile paths are prefixes / siblings of one
+// another).  A lane's alignment counts as "good for all" when it is good for more than
+// half of the paths -- one wave-wide popcount per item -- and the paths where that is
+// wrong are exceptions, settled bit by bit over the union of the wave's exception bits
+// (few: a substituted step, a path that ends earlier).
+template <bool W>
+struct Acc3 {
+    uint32_t good = 0, bad = 0;          // lane p: totals of tile path p (may go through negative partial sums)
+    uint32_t fg = 0, fb = 0;             // (uniform, or per lane with weights) good / bad for all paths of the pass
+    __device__ __forceinline__ void add(uint32_t good_mask, uint32_t bad_mask, const Tile3 &tv, uint32_t w, int lane)
     {
-        const bool isg = good_mask == sub, isb = bad_mask == sub;
-        fg += isg ? w : 0u;
-        fb += isb ? w : 0u;
-        const bool mixed = !isg && !isb && (good_mask | bad_mask) != 0u;
-        if (WAVE_ANY(mixed)) {
-            const int lane = threadIdx.x & (WAVE - 1);
-            const uint32_t cg = mixed ? good_mask : 0u, cb = mixed ? bad_mask : 0u;
-            uint32_t any = cg | cb;
-#pragma unroll
-            for (int o = 1; o < WAVE; o <<= 1) any |= (uint32_t)__shfl_xor((int)any, o, WAVE);
-            any = (uint32_t)__builtin_amdgcn_readfirstlane((int)any);
-            while (any) {
-                const int p = __builtin_ctz(any);
-                any &= any - 1u;
-                const uint32_t sg = wave_sum_u32(((cg >> p) & 1u) ? w : 0u);
-                const uint32_t sb = wave_sum_u32(((cb >> p) & 1u) ? w : 0u);
+        const bool isg = (uint32_t)__builtin_popcount(good_mask) > tv.half;
+        const bool isb = (uint32_t)__builtin_popcount(bad_mask) > tv.half;
+        const lanemask mg = WAVE_MASK(isg), mb = WAVE_MASK(isb);
+        if constexpr (W) {
+            fg += isg ? w : 0u;
+            fb += isb ? w : 0u;
+        } else {
+            fg += (uint32_t)__popcll(mg);
+            fb += (uint32_t)__popcll(mb);
+        }
+        const uint32_t xg = good_mask ^ (isg ? tv.sub_mask : 0u), xb = bad_mask ^ (isb ? tv.sub_mask : 0u);
+        lanemask any_x = WAVE_MASK((xg | xb) != 0u);
+        asm volatile("" : "+s"(any_x));          // (keeps the reduction below out of the common path)
+        if (__builtin_expect(any_x != 0ull, 0)) {
+            uint32_t u = wave_or_dpp(xg | xb);
+            while (u) {
+                const int p = __builtin_ctz(u);
+                u &= u - 1u;
+                const bool eg = ((xg >> p) & 1u) != 0u, eb = ((xb >> p) & 1u) != 0u;
+                uint32_t dg, db;
+                if constexpr (W) {
+                    dg = wave_add_dpp(eg ? (isg ? 0u - w : w) : 0u);
+                    db = wave_add_dpp(eb ? (isb ? 0u - w : w) : 0u);
+                } else {
+                    const lanemask g = WAVE_MASK(eg), b = WAVE_MASK(eb);
+                    dg = (uint32_t)__popcll(g & ~mg) - (uint32_t)__popcll(g & mg);
+                    db = (uint32_t)__popcll(b & ~mb) - (uint32_t)__popcll(b & mb);
+                }
                 if (lane == p) {
-                    good += sg;
-                    bad += sb;
+                    good += dg;
+                    bad += db;
                 }
             }
         }
     }
-    __device__ __forceinline__ void finish(uint32_t sub)
+    __device__ __forceinline__ void finish(const Tile3 &tv, int lane)
     {
-        const int lane = threadIdx.x & (WAVE - 1);
-        const uint32_t sg = wave_sum_u32(fg), sb = wave_sum_u32(fb);
-        if ((sub >> lane) & 1u) {
+        uint32_t sg = fg, sb = fb;
+        if constexpr (W) {
+            sg = wave_add_dpp(fg);
+            sb = wave_add_dpp(fb);
+        }
+        if ((tv.sub_mask >> lane) & 1u) {
             good += sg;
             bad += sb;
         }
@@ -4137,140 +4194,152 @@ struct Counts3W {
     }
 };
 
-template <int P0>
+template <int P0, bool W>
 struct Item3Regs {
-    uint32_t np[P0 > 0 ? P0 : 1];
     uint32_t key, w;
+    uint32_t np[P0 > 0 ? P0 : 1];
     uint32_t it;                 // (uniform) the item
 };
 
-// One item against the tile: the decided part.  pm: AND of the node masks of the lane's
-// alignment (bits 0..30: every node is on tile path p; bit 31: none is the tile's first node).
-template <bool W, typename Counts>
-__device__ __forceinline__ void scan3_decide(const Scan3Args &a, const Tile3 &tv, const LenSeg &sg,
-                                             uint32_t key, uint32_t w, uint32_t it, uint32_t pm,
-                                             uint2 e, uint32_t slot, int lane, Counts &wc)
+// The rare part of an item: lanes whose alignment is not a subpath of some tile path but
+// touches the tile's first node.  The traceback stays free only if a proper suffix of B
+// (or of rc(B)) equals a prefix of the path; survivors of this exact test go to the DP
+// kernels (as in k_scan2; everything is read from HBM here).
+__device__ __forceinline__ uint32_t scan3_triage(const Scan3Args &a, const Tile3 &tv, const Seg3 &sg,
+                                                 uint32_t it, uint32_t open, bool has_a0, int tile_rel, int lane)
 {
+    const Scan3Cold c = *a.cold;
     const int M = (int)sg.m;
-    const bool valid = key != KEY_EMPTY;
-    uint32_t pass = a.filter ? (pm & 0x7FFFFFFFu) : 0x7FFFFFFFu;
-    pass = valid ? (pass & tv.sub_mask) : 0u;
-    const bool has_a0 = !tv.uniform_a0 || (pm & NOT_A0) == 0u;
-    const uint32_t gt = pass & tv.gt_mask;          // src/alignments.cpp:500: m > n -> good
-    const uint32_t todo = pass & ~tv.gt_mask;
-    // ---- which of the tile's paths contain exactly this step sequence ----
-    const bool searching = todo != 0u;
-    while (true) {
-        const bool stop = !searching || e.x == key || e.x == KEY_EMPTY;
-        if (!WAVE_ANY(!stop)) break;
-        slot = stop ? slot : ((slot + 1u) & tv.h_mask);
-        const uint2 e2 = tv.table[slot];
-        e.x = stop ? e.x : e2.x;
-        e.y = stop ? e.y : e2.y;
-    }
-    const uint32_t fmask = (searching && e.x == key) ? (e.y & todo) : 0u;
-    const uint32_t good_mask = gt | fmask;
-    const uint32_t open = todo & ~fmask;
-    uint32_t bad_mask = open;
-    // ---- start-overhang triage (as in k_scan2; rare: the alignment must touch the tile's
-    // first node): survivors go to the exact DP ----
-    if (WAVE_ANY(open != 0u && has_a0)) {
-        uint32_t cfw = 0, crc = 0;
-        const uint16_t *bp = a.items.steps +
-                             ((size_t)sg.step_base + (size_t)(it - sg.item_lo) * (uint32_t)M) * WAVE + lane;
-        uint32_t want = (open != 0u && has_a0) ? open : 0u;
-#pragma unroll
-        for (int o = 1; o < WAVE; o <<= 1) want |= (uint32_t)__shfl_xor((int)want, o, WAVE);
-        want = (uint32_t)__builtin_amdgcn_readfirstlane((int)want);
-        while (want) {
-            const int p = __builtin_ctz(want);
-            want &= want - 1u;
-            const bool mine = ((open >> p) & 1u) != 0u && has_a0;
-            const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)tv.hdr_a0, p);
-            const uint32_t *pstep32 = reinterpret_cast<const uint32_t *>(
-                a.images + (size_t)(tv.path0 + p) * a.L.total + a.L.step_at());
-            bool cand_fw = false, cand_rc = false;
-            for (int t = 0; t < M; ++t) {
-                const uint32_t bt = bp[t * WAVE];
-                const bool live_fw = mine && t >= 1 && bt == a0;
-                if (WAVE_ANY(live_fw)) cand_fw |= tail_equals(bp, t, 1, M - t, 0u, pstep32, live_fw);
-                const bool live_rc = mine && t < M - 1 && (bt ^ 1u) == a0;
-                if (WAVE_ANY(live_rc)) cand_rc |= tail_equals(bp, t, -1, t + 1, 1u, pstep32, live_rc);
-            }
-            cfw |= cand_fw ? (1u << p) : 0u;
-            crc |= cand_rc ? (1u << p) : 0u;
+    uint32_t cfw = 0, crc = 0;
+    const uint16_t *bp = c.item_steps + ((size_t)sg.step_base + (size_t)(it - sg.item_lo) * (uint32_t)M) * WAVE + lane;
+    uint32_t want = wave_or_dpp(has_a0 ? open : 0u);
+    // the test reads the first M - 1 steps of a path: tile paths that share them with the
+    // tile's first path (nearly always all of them) are decided together
+    uint32_t my_lcp = 0;
+    if (lane < tv.tile_paths) my_lcp = a.tile_hdr[(size_t)tile_rel * T3_THDR_WORDS + 64 + lane];
+    const uint32_t class0 = (uint32_t)WAVE_MASK(lane < tv.tile_paths && (int)my_lcp >= M - 1);
+    while (want) {
+        const int p = __builtin_ctz(want);
+        const uint32_t grp = ((class0 >> p) & 1u) ? class0 : (1u << p);
+        want &= ~grp;
+        const uint32_t mine_bits = has_a0 ? (open & grp) : 0u;
+        const bool mine = mine_bits != 0u;
+        const uint32_t a0 = a.tile_hdr[(size_t)tile_rel * T3_THDR_WORDS + 32 + p];
+        const uint32_t *pstep32 = reinterpret_cast<const uint32_t *>(
+            c.images + (size_t)(tv.path0 + p) * c.L.total + c.L.step_at());
+        bool cand_fw = false, cand_rc = false;
+        for (int t = 0; t < M; ++t) {
+            const uint32_t bt = bp[t * WAVE];
+            const bool live_fw = mine && t >= 1 && bt == a0;
+            if (WAVE_ANY(live_fw)) cand_fw |= tail_equals(bp, t, 1, M - t, 0u, pstep32, live_fw);
+            const bool live_rc = mine && t < M - 1 && (bt ^ 1u) == a0;
+            if (WAVE_ANY(live_rc)) cand_rc |= tail_equals(bp, t, -1, t + 1, 1u, pstep32, live_rc);
         }
-        bad_mask &= ~(cfw | crc);
-        push_item_pairs(a.worklist, a.wl_count, a.wl_capacity, a.wl_hist, a.status, a.n_paths, cfw, crc,
-                        lane, (uint32_t)tv.path0, tv.tile_paths, it * WAVE + (uint32_t)lane, M);
+        cfw |= cand_fw ? mine_bits : 0u;
+        crc |= cand_rc ? mine_bits : 0u;
     }
-    wc.add(good_mask, bad_mask, tv.sub_mask, w);
+    push_item_pairs(c.worklist, c.wl_count, c.wl_capacity, c.wl_hist, c.status, c.n_paths, cfw, crc, lane,
+                    (uint32_t)tv.path0, tv.tile_paths, it * WAVE + (uint32_t)lane, M);
+    return cfw | crc;
 }
 
-template <int P0, bool W, bool NMG, typename Counts>
-__device__ __forceinline__ void scan3_item(const Scan3Args &a, const Tile3 &tv, const LenSeg &sg,
-                                           const Item3Regs<P0> &r, int lane, Counts &wc)
+// One item against the tile, from the lane's registers: key, pm = AND of the node masks of
+// the lane's alignment (bits 0..30: every node is on tile path p -- the filter of
+// src/eval.cpp:81-91; bit 31: none is the tile's first node), e = the table entry of the
+// key's home slot.
+template <bool W>
+__device__ __forceinline__ void scan3_decide(const Scan3Args &a, const Tile3 &tv, const Seg3 &sg,
+                                             uint32_t key, uint32_t w, uint32_t it, uint32_t pm, uint2 e,
+                                             int tile_rel, int lane, Acc3<W> &acc)
 {
-    // the first probe goes out together with the node-mask reads
-    const uint32_t slot = r.key & tv.h_mask;
-    const uint2 e = tv.table[slot];
+    const uint32_t pass = pm & tv.sub_mask;
+    const uint32_t todo = pass & ~tv.gt_mask;       // (src/alignments.cpp:500: m > n -> good)
+    // ---- which of the tile's paths contain exactly this step sequence ----
+    if (__builtin_expect(WAVE_ANY(todo != 0u && e.x != key && e.x != KEY_EMPTY), 0)) {      // (the home slot is taken)
+        uint32_t slot = key & tv.h_mask;
+        bool more = todo != 0u && e.x != key && e.x != KEY_EMPTY;
+        while (WAVE_ANY(more)) {
+            slot = (slot + 1u) & tv.h_mask;
+            const uint2 e2 = lds_entry(tv.tab_base + (slot << 3));
+            e.x = more ? e2.x : e.x;
+            e.y = more ? e2.y : e.y;
+            more = more && e.x != key && e.x != KEY_EMPTY;
+        }
+    }
+    const uint32_t have = (e.x == key ? e.y : 0u) | tv.gt_mask;
+    const uint32_t good_mask = pass & have;
+    const uint32_t open = pass & ~have;
+    uint32_t bad_mask = open;
+    const bool has_a0 = (int32_t)pm >= 0;
+    if (__builtin_expect(WAVE_ANY(open != 0u && has_a0), 0))
+        bad_mask &= ~scan3_triage(a, tv, sg, it, open, has_a0, tile_rel, lane);
+    acc.add(good_mask, bad_mask, tv, w, lane);
+}
+
+template <int P0, bool W, bool NMG>
+__device__ __forceinline__ void scan3_item(const Scan3Args &a, const Tile3 &tv, const Seg3 &sg,
+                                           const Item3Regs<P0, W> &r, int tile_rel, int lane, Acc3<W> &acc)
+{
+    // the probe goes out together with the node-mask reads: one LDS round trip
+    const uint2 e = lds_entry(tv.tab_base + ((r.key & tv.h_mask) << 3));
     uint32_t pm = 0xFFFFFFFFu;
 #pragma unroll
     for (int k = 0; k < P0; ++k) {
-        pm &= tv.nodemask[r.np[k] & 0xFFFFu];
-        pm &= tv.nodemask[r.np[k] >> 16];
+        pm &= nm_read<NMG>(tv, r.np[k] & 0xFFFFu);
+        pm &= nm_read<NMG>(tv, r.np[k] >> 16);
     }
-    scan3_decide<W>(a, tv, sg, r.key, r.w, r.it, pm, e, slot, lane, wc);
+    scan3_decide<W>(a, tv, sg, r.key, r.w, r.it, pm, e, tile_rel, lane, acc);
 }
 
 // The wave's items of one segment chunk, 64 at a time: one ballot drops the items none
-// of whose lanes can pass the filter.  P0 = ceil(M / 2) pair dwords per lane in registers
+// of whose lanes can pass the filter.  P0 = ceil(M / 2) offset dwords per lane in registers
 // (two sets, loaded one item ahead), or 0: any length, loaded where it is used.
-template <int P0, bool W, bool NMG, typename Counts>
-__device__ __forceinline__ void scan3_items(const Scan3Args &a, const Tile3 &tv, const LenSeg &sg,
-                                            int chunk, int wave, int lane, Counts &wc)
+template <int P0, bool W, bool NMG>
+__device__ __forceinline__ void scan3_items(const Scan3Args &a, const Tile3 &tv, const Seg3 &sg,
+                                            int chunk, int wave, int tile_rel, int lane, Acc3<W> &acc)
 {
     const int n_chunks = (int)sg.n_chunks;
     const int item_stride = SCAN2_WAVES * n_chunks;
     const int P0rt = ((int)sg.m + 1) / 2;
+    const int R = 1 + P0rt + (W ? 1 : 0);
     const uint32_t ulane = (uint32_t)lane;
     for (int it0 = (int)sg.item_lo + chunk + wave * n_chunks; it0 < (int)sg.item_hi;
          it0 += WAVE * item_stride) {
         const int my_it = it0 + lane * item_stride;
-        const bool mine = my_it < (int)sg.item_hi;
-        bool keep = mine;
-        if (a.filter && mine) {
-            const uint32_t common = a.items.common[my_it];
+        bool keep = my_it < (int)sg.item_hi;
+        if (keep) {
+            const uint32_t common = a.common[my_it];
             if (common != NO_COMMON_NODE) {
-                const uint32_t m1 = tv.nodemask[common & 0x7FFFu], m2 = tv.nodemask[common >> 16];
+                const uint32_t m1 = nm_read<NMG>(tv, (common & 0x7FFFu) << (NMG ? 2 - tv.nm_shift : 2)),
+                               m2 = nm_read<NMG>(tv, (common >> 16) << (NMG ? 2 - tv.nm_shift : 2));
                 keep = (((common & COMMON_EITHER) ? (m1 | m2) : (m1 & m2)) & tv.sub_mask) != 0u;
             }
         }
         lanemask todo = WAVE_MASK(keep);
         if (todo == 0) continue;
         if constexpr (P0 > 0) {
-            auto load_item = [&](int src_in, Item3Regs<P0> &r) {
+            auto load_item = [&](int src_in, Item3Regs<P0, W> &r) {
                 const int src = __builtin_amdgcn_readfirstlane(src_in);
                 const uint32_t it = (uint32_t)(it0 + src * item_stride);
                 r.it = it;
-                r.key = sgpr_ptr(a.item_key + (size_t)it * WAVE)[ulane];
-                r.w = W ? sgpr_ptr(a.items.weight + (size_t)it * WAVE)[ulane] : 1u;
                 const GLOBAL_AS uint32_t *pp =
-                    sgpr_ptr(a.npairs + ((size_t)sg.p0_base + (size_t)(it - sg.item_lo) * P0) * WAVE) + ulane;
+                    sgpr_ptr(a.rec3 + ((size_t)sg.r3_base + (size_t)(it - sg.item_lo) * (P0 + 1 + (W ? 1 : 0))) * WAVE) + ulane;
+                r.key = pp[0];
 #pragma unroll
-                for (int k = 0; k < P0; ++k) r.np[k] = pp[k * WAVE];
+                for (int k = 0; k < P0; ++k) r.np[k] = pp[(k + 1) * WAVE];
+                r.w = W ? pp[(P0 + 1) * WAVE] : 1u;
             };
-            Item3Regs<P0> ra, rb;
+            Item3Regs<P0, W> ra, rb;
             load_item(__builtin_ctzll(todo), ra);
             while (true) {
                 lanemask rest = todo & (todo - 1);
                 load_item(__builtin_ctzll(rest ? rest : todo), rb);
-                scan3_item<P0, W, NMG>(a, tv, sg, ra, lane, wc);
+                scan3_item<P0, W, NMG>(a, tv, sg, ra, tile_rel, lane, acc);
                 if (rest == 0) break;
                 todo = rest;
                 rest = todo & (todo - 1);
                 load_item(__builtin_ctzll(rest ? rest : todo), ra);
-                scan3_item<P0, W, NMG>(a, tv, sg, rb, lane, wc);
+                scan3_item<P0, W, NMG>(a, tv, sg, rb, tile_rel, lane, acc);
                 if (rest == 0) break;
                 todo = rest;
             }
@@ -4278,24 +4347,21 @@ __device__ __forceinline__ void scan3_items(const Scan3Args &a, const Tile3 &tv,
             for (; todo != 0; todo &= todo - 1) {
                 const int src = __builtin_amdgcn_readfirstlane(__builtin_ctzll(todo));
                 const uint32_t it = (uint32_t)(it0 + src * item_stride);
-                const uint32_t key = a.item_key[(size_t)it * WAVE + ulane];
-                const uint32_t w = W ? a.items.weight[(size_t)it * WAVE + ulane] : 1u;
-                const uint32_t slot = key & tv.h_mask;
-                const uint2 e = tv.table[slot];
-                const uint32_t *pp = a.npairs + ((size_t)sg.p0_base + (size_t)(it - sg.item_lo) * P0rt) * WAVE + ulane;
+                const uint32_t *pp = a.rec3 + ((size_t)sg.r3_base + (size_t)(it - sg.item_lo) * R) * WAVE + ulane;
+                const uint32_t key = pp[0];
+                const uint32_t w = W ? pp[(size_t)(P0rt + 1) * WAVE] : 1u;
+                const uint2 e = lds_entry(tv.tab_base + ((key & tv.h_mask) << 3));
                 uint32_t pm = 0xFFFFFFFFu;
                 for (int k = 0; k < P0rt; ++k) {
-                    const uint32_t x = pp[(size_t)k * WAVE];
-                    pm &= tv.nodemask[x & 0xFFFFu];
-                    pm &= tv.nodemask[x >> 16];
+                    const uint32_t x = pp[(size_t)(k + 1) * WAVE];
+                    pm &= nm_read<NMG>(tv, x & 0xFFFFu);
+                    pm &= nm_read<NMG>(tv, x >> 16);
                 }
-                scan3_decide<W>(a, tv, sg, key, w, it, pm, e, slot, lane, wc);
+                scan3_decide<W>(a, tv, sg, key, w, it, pm, e, tile_rel, lane, acc);
             }
         }
     }
 }
-
-constexpr int SCAN3_REG_P0 = 6;      // alignments of up to 12 steps: node pairs in registers
 
 template <bool W, bool NMG>
 __global__ __launch_bounds__(SCAN2_THREADS, SCAN2_WAVES_PER_SIMD) void k_scan3(Scan3Args a)
@@ -4306,11 +4372,11 @@ __global__ __launch_bounds__(SCAN2_THREADS, SCAN2_WAVES_PER_SIMD) void k_scan3(S
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tile_rel = blockIdx.x % a.n_tiles;
     // (segment, chunk) <- the workgroup's row, as in k_scan2
-    LenSeg sg;
+    Seg3 sg;
     int chunk, seg;
     {
         const int y = blockIdx.x / a.n_tiles;
-        LenSeg mine{0u, 0u, 0u, 0u, 0u, 0u};
+        Seg3 mine{0u, 0u, 0u, 0u, 0u, 0u};
         if (lane < a.n_segs) mine = a.segs[lane];
         const uint32_t c = lane < a.n_segs
                                ? seg_chunks(mine.item_hi - mine.item_lo, a.chunk_mult, a.chunk_inv_min)
@@ -4328,40 +4394,33 @@ __global__ __launch_bounds__(SCAN2_THREADS, SCAN2_WAVES_PER_SIMD) void k_scan3(S
         sg.m = (uint32_t)__builtin_amdgcn_readlane((int)mine.m, seg);
         sg.n_chunks = (uint32_t)__builtin_amdgcn_readlane((int)c, seg);
         sg.step_base = (uint32_t)__builtin_amdgcn_readlane((int)mine.step_base, seg);
-        sg.p0_base = (uint32_t)__builtin_amdgcn_readlane((int)mine.p0_base, seg);
+        sg.r3_base = (uint32_t)__builtin_amdgcn_readlane((int)mine.r3_base, seg);
         chunk = y - (int)__builtin_amdgcn_readlane((int)(incl - c), seg);
     }
     const int M = (int)sg.m;
-    const int v2 = a.L.v2;
+    const int v2p = a.v2p;
     Tile3 tv;
     tv.path0 = (a.tile0 + tile_rel) * a.tile;
     tv.tile_paths = min(a.tile, a.n_paths - tv.path0);
     tv.h_mask = a.h_slots - 1u;
-    // LDS: node masks first (address = node * 4: no base to add), then the table
-    uint32_t *nodemask = lds32;
-    uint32_t *tab = lds32 + (NMG ? 0 : v2);
+    tv.nm_shift = a.nm_shift;
+    // LDS: node masks first (address = the record's byte offset: no base to add), then the table
+    uint32_t *tab = lds32 + (NMG ? 0 : v2p);
     uint32_t *misc = tab + 2 * a.h_slots;
-    const uint32_t *gmask = a.tile_masks + (size_t)tile_rel * v2;
-    tv.nodemask = NMG ? gmask : nodemask;
-    tv.table = reinterpret_cast<const uint2 *>(tab);
+    const uint32_t *gmask = a.tile_masks + (size_t)tile_rel * v2p;
+    tv.gmask = reinterpret_cast<const char *>(gmask);
+    tv.tab_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)tab;
     if constexpr (!NMG) {
         // straight from global memory into LDS (lane l of a wave-instruction lands at its
         // uniform LDS base + 4 l)
-        for (int o = wave * WAVE; o < v2; o += SCAN2_THREADS)
-            if (o + lane < v2)
+        for (int o = wave * WAVE; o < v2p; o += SCAN2_THREADS)
+            if (o + lane < v2p)
                 __builtin_amdgcn_global_load_lds(
                     (const __attribute__((address_space(1))) void *)(gmask + o + lane),
-                    (__attribute__((address_space(3))) void *)(nodemask + o), 4, 0, 0);
+                    (__attribute__((address_space(3))) void *)(lds32 + o), 4, 0, 0);
     }
-    tv.hdr_n = 0;
-    tv.hdr_a0 = STEP_NOMATCH;
-    if (lane < tv.tile_paths) {
-        const uint16_t *img = a.images + (size_t)(tv.path0 + lane) * a.L.total;
-        tv.hdr_n = img[a.L.len_at()];
-        tv.hdr_a0 = img[a.L.step_at()];
-    }
-    const uint32_t tile_a0 = (uint32_t)__builtin_amdgcn_readlane((int)tv.hdr_a0, 0);
-    tv.uniform_a0 = WAVE_MASK(lane < tv.tile_paths && tv.hdr_a0 != tile_a0) == 0ull;
+    int hdr_n = 0;
+    if (lane < tv.tile_paths) hdr_n = (int)a.tile_hdr[(size_t)tile_rel * T3_THDR_WORDS + lane];
     const uint32_t *hdr = a.hdr + ((size_t)tile_rel * a.n_segs_total + a.seg0 + seg) * T3_HDR_WORDS;
     const uint2 *list = a.list + ((size_t)tile_rel * a.n_segs_total + a.seg0 + seg) * a.stride;
     const int n_passes = (int)hdr[0];
@@ -4384,29 +4443,14 @@ __global__ __launch_bounds__(SCAN2_THREADS, SCAN2_WAVES_PER_SIMD) void k_scan3(S
             tab[2u * slot + 1u] = en.y;
         }
         tv.sub_mask = ((1u << t1) - 1u) & ~((1u << t0) - 1u);
-        tv.gt_mask = 0;
-        for (int t = t0; t < t1; ++t)
-            if (__builtin_amdgcn_readlane(tv.hdr_n, t) < M) tv.gt_mask |= 1u << t;
+        tv.half = (uint32_t)__builtin_popcount(tv.sub_mask) / 2u;
+        tv.gt_mask = (uint32_t)WAVE_MASK(lane >= t0 && lane < t1 && hdr_n < M);
         if constexpr (!NMG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the node masks have landed
         __syncthreads();
-        LenSeg sgl = sg;
+        Seg3 sgl = sg;
         if (a.debug == 1) sgl.item_hi = sgl.item_lo;      // timing probe: no items
-#define GFAL_RUN3(PP)                                                           \
-    do {                                                                        \
-        if constexpr (W) {                                                      \
-            Counts3W wc;                                                        \
-            scan3_items<PP, true, NMG>(a, tv, sgl, chunk, wave, lane, wc);      \
-            wc.finish(tv.sub_mask);                                             \
-            cnt_good += wc.good;                                                \
-            cnt_bad += wc.bad;                                                  \
-        } else {                                                                \
-            Counts3 wc;                                                         \
-            scan3_items<PP, false, NMG>(a, tv, sgl, chunk, wave, lane, wc);     \
-            wc.finish(tv.sub_mask);                                             \
-            cnt_good += wc.good;                                                \
-            cnt_bad += wc.bad;                                                  \
-        }                                                                       \
-    } while (0)
+        Acc3<W> acc;
+#define GFAL_RUN3(PP) scan3_items<PP, W, NMG>(a, tv, sgl, chunk, wave, tile_rel, lane, acc)
         switch ((M + 1) / 2) {
         case 1: GFAL_RUN3(1); break;
         case 2: GFAL_RUN3(2); break;
@@ -4417,6 +4461,9 @@ __global__ __launch_bounds__(SCAN2_THREADS, SCAN2_WAVES_PER_SIMD) void k_scan3(S
         default: GFAL_RUN3(0); break;
         }
 #undef GFAL_RUN3
+        acc.finish(tv, lane);
+        cnt_good += acc.good;
+        cnt_bad += acc.bad;
     }
     // workgroup reduction through LDS (the table is dead now), then one atomic per
     // counter per workgroup
@@ -4463,13 +4510,18 @@ struct gfal_scorer {
     uint32_t *d_item_weight = nullptr;   // Items::weight (dedup scorers)
     uint32_t *d_item_hash = nullptr;     // [n_items * 64] whash of every lane (k_scan2)
     uint32_t *d_item_pairs0 = nullptr;   // Scan2Args::pairs0
-    uint32_t *d_item_npairs = nullptr;   // Scan3Args::npairs
-    uint32_t *d_item_key = nullptr;      // Scan3Args::item_key (content-table index of every lane)
+    uint32_t *d_rec3 = nullptr;          // Scan3Args::rec3 (item records: key, node offsets, weight)
+    uint32_t *d_item_r3 = nullptr;       // [n_items] where every item's record starts (units of 64 dwords)
+    Seg3 *d_segs3 = nullptr;             // the segments as k_scan3 reads them
+    bool np_scaled = true;               // record offsets are byte offsets into the node masks (else node indices)
     uint4 *d_ct_rec = nullptr;           // ContentTable::rec
-    // k_tile / k_scan3 per-call buffers: node masks per tile, window lists per (tile, length)
-    uint32_t *d_tile_masks = nullptr, *d_t3_hdr = nullptr;
+    // k_tile / k_scan3 per-call buffers: node masks and header per tile, window lists per
+    // (tile, length), the cold arguments
+    uint32_t *d_tile_masks = nullptr, *d_t3_hdr = nullptr, *d_tile_hdr = nullptr;
     uint2 *d_t3_list = nullptr;
-    size_t tile_masks_cap = 0, t3_hdr_cap = 0, t3_list_cap = 0;
+    size_t tile_masks_cap = 0, t3_hdr_cap = 0, t3_list_cap = 0, tile_hdr_cap = 0;
+    Scan3Cold *d_cold = nullptr, *h_cold = nullptr;      // h_cold: pinned ring of COLD_RING structs
+    int cold_next = 0;
     // k_scan2 takes the items of the well-populated alignment lengths: they come
     // first in the item order, one contiguous segment per length; the items of
     // the rare lengths follow and are scanned by k_scan
@@ -4603,7 +4655,8 @@ void free_scorer(gfal_scorer *s)
     (void)hipSetDevice(s->device);
     void *bufs[] = {s->d_item_pairs, s->d_item_pbase, s->d_item_common, s->d_item_hdr, s->d_item_weight,
                     s->d_item_hash, s->d_item_pairs0, s->d_lids, s->d_segs,
-                    s->d_item_npairs, s->d_item_key, s->d_ct_rec, s->d_tile_masks, s->d_t3_hdr, s->d_t3_list,
+                    s->d_rec3, s->d_item_r3, s->d_segs3, s->d_ct_rec, s->d_tile_masks, s->d_t3_hdr, s->d_t3_list,
+                    s->d_tile_hdr, s->d_cold,
                     s->d_len_bins, s->d_order,
                     s->d_counts_slot,
                     s->d_node_local, s->d_node_hist, s->d_item_steps, s->d_item_base,
@@ -4617,6 +4670,7 @@ void free_scorer(gfal_scorer *s)
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     if (s->graph_exec) (void)hipGraphExecDestroy(s->graph_exec);
+    if (s->h_cold) (void)hipHostFree(s->h_cold);
     if (s->h_in) (void)hipHostFree(s->h_in);
     if (s->h_out) (void)hipHostFree(s->h_out);
     for (auto &set : s->ev)
@@ -5185,7 +5239,26 @@ static int create_impl(const int32_t *aln_off, const int32_t *aln_steps, int64_t
     std::vector<uint32_t> item_weight(dedup ? src.size() * WAVE : 0, 0u);
     std::vector<uint32_t> item_hash(src.size() * WAVE, 0u);
     std::vector<uint32_t> item_pairs0((size_t)n_pairs0, 0xFFFFFFFFu);
-    std::vector<uint32_t> item_npairs((size_t)n_pairs0, 0u);      // Scan3Args::npairs
+    // k_scan3's item records (see Seg3): the key is filled in on the device (k_ct_build)
+    const int v2_local = (n_local + 1) & ~1;
+    const bool np_scaled = v2_local * 4 + 8 <= 0xFFFF;
+    const uint32_t np_zero = (uint32_t)v2_local * (np_scaled ? 4u : 1u);      // the mask word that stays zero
+    std::vector<uint32_t> item_r3(src.size(), 0u);
+    std::vector<Seg3> segs3;
+    uint64_t n_rec3 = 0;
+    for (const LenSeg &sg : segs) {
+        const uint32_t R = 1u + (sg.m + 1) / 2 + (dedup ? 1u : 0u);
+        segs3.push_back(Seg3{sg.item_lo, sg.item_hi, sg.m, 1u, sg.step_base, (uint32_t)(n_rec3 / WAVE)});
+        for (uint32_t it = sg.item_lo; it < sg.item_hi; ++it) {
+            item_r3[it] = (uint32_t)(n_rec3 / WAVE);
+            n_rec3 += (uint64_t)R * WAVE;
+        }
+    }
+    if (n_rec3 / WAVE >= ((uint64_t)1 << 32)) {
+        set_err("shard too large for 32-bit item addressing");
+        return GFAL_E_RANGE;
+    }
+    std::vector<uint32_t> rec3((size_t)n_rec3, np_zero | (np_zero << 16));
     // where every item's pairs0 block starts (units of 64 dwords): its segment's base
     // plus its rank in the segment times ceil(m / 2)
     std::vector<uint32_t> item_p0base(src.size(), 0u);
@@ -5222,14 +5295,16 @@ static int create_impl(const int32_t *aln_off, const int32_t *aln_steps, int64_t
                             (uint32_t)px[2 * k + 1] |
                             ((2 * k + 2 < m) ? ((uint32_t)px[2 * k + 2] << 16) : 0u);
                     uint32_t *pairs0 = item_pairs0.data() + (size_t)item_p0base[it] * WAVE;
-                    uint32_t *npairs = item_npairs.data() + (size_t)item_p0base[it] * WAVE;
+                    uint32_t *r3 = rec3.data() + (size_t)item_r3[it] * WAVE;
+                    const uint32_t np_mul = np_scaled ? 4u : 1u;
                     for (int k = 0; k < (m + 1) / 2; ++k) {
                         pairs0[(size_t)k * WAVE + l] =
                             (uint32_t)px[2 * k] | ((2 * k + 1 < m) ? ((uint32_t)px[2 * k + 1] << 16) : 0xFFFF0000u);
-                        const uint32_t n_lo = (uint32_t)px[2 * k] >> 1;
-                        npairs[(size_t)k * WAVE + l] =
-                            n_lo | ((2 * k + 1 < m ? (uint32_t)px[2 * k + 1] >> 1 : n_lo) << 16);
+                        const uint32_t n_lo = ((uint32_t)px[2 * k] >> 1) * np_mul;
+                        r3[(size_t)(k + 1) * WAVE + l] =
+                            n_lo | ((2 * k + 1 < m ? ((uint32_t)px[2 * k + 1] >> 1) * np_mul : n_lo) << 16);
                     }
+                    if (dedup) r3[(size_t)((m + 1) / 2 + 1) * WAVE + l] = w;
                     slot_orig[it * WAVE + (size_t)l] = is.idx[l];
                 }
                 // nodes every lane has: the first and the last such node of lane 0
@@ -5378,7 +5453,12 @@ static int create_impl(const int32_t *aln_off, const int32_t *aln_steps, int64_t
     if (dedup && (rc = dev_upload(&s->d_item_weight, item_weight))) return fail(rc);
     if ((rc = dev_upload(&s->d_item_hash, item_hash))) return fail(rc);
     if ((rc = dev_upload(&s->d_item_pairs0, item_pairs0))) return fail(rc);
-    if ((rc = dev_upload(&s->d_item_npairs, item_npairs))) return fail(rc);
+    for (size_t it = 0; it < src.size(); ++it)
+        for (int l = 0; l < WAVE; ++l) rec3[(size_t)item_r3[it] * WAVE + l] = KEY_EMPTY;
+    if ((rc = dev_upload(&s->d_rec3, rec3))) return fail(rc);
+    if ((rc = dev_upload(&s->d_item_r3, item_r3))) return fail(rc);
+    if ((rc = dev_upload(&s->d_segs3, segs3))) return fail(rc);
+    s->np_scaled = np_scaled;
     if ((rc = dev_upload(&s->d_segs, segs))) return fail(rc);
     s->segs = segs;
     s->n_hash_items = n_hash_items;
@@ -5530,6 +5610,7 @@ static int ensure_call_buffers(gfal_scorer *s, int32_t n_paths, const ImageLayou
 
 // k_tile_masks + k_tile + k_scan3 over the segments [0, n_segs) of the scorer, in slabs of
 // tiles that fit the window-list buffer.
+constexpr int COLD_RING = 64;
 static int launch_scan3(gfal_scorer *s, hipStream_t st, const Items &items, const ImageLayout &L,
                         int32_t n_paths, int32_t max_path_len, int filter, int n_segs, int n_items3,
                         int want_groups, int slots, uint32_t *d_counts, unsigned long long *wl_count,
@@ -5540,23 +5621,20 @@ static int launch_scan3(gfal_scorer *s, hipStream_t st, const Items &items, cons
     // LDS of a k_scan3 workgroup: node masks (4 bytes per node) + table (8 bytes per slot).
     // The table holds at least one path's windows at load 1/2 (4096 slots); many nodes:
     // the masks stay in HBM (read through L1 / L2)
-    const size_t mask_bytes = (size_t)L.v2 * sizeof(uint32_t);
+    const int v2p = L.v2 + 2;
+    const size_t mask_bytes = (size_t)v2p * sizeof(uint32_t);
     uint32_t h_slots = 8192;
-    bool nmg = false;
+    bool nmg = !s->np_scaled;
     if (mask_bytes + (size_t)h_slots * 8 + 256 > (size_t)LDS_BUDGET) h_slots = 4096;
-    if (mask_bytes + (size_t)h_slots * 8 + 256 > (size_t)LDS_BUDGET) {
-        nmg = true;
-        h_slots = 8192;
-    }
+    if (mask_bytes + (size_t)h_slots * 8 + 256 > (size_t)LDS_BUDGET) nmg = true;
+    if (const char *env = getenv("GFAL_SCAN3_NMG")) nmg = nmg || atoi(env) != 0;
+    if (nmg) h_slots = 8192;
     if (const char *env = getenv("GFAL_SCAN3_SLOTS")) {
         const int v = atoi(env);
-        if (v == 4096 || v == 8192) h_slots = (uint32_t)v;
+        if ((v == 4096 || v == 8192) && (nmg ? 0 : mask_bytes) + (size_t)v * 8 + 256 <= (size_t)LDS_BUDGET)
+            h_slots = (uint32_t)v;
     }
-    if (const char *env = getenv("GFAL_SCAN3_NMG")) nmg = atoi(env) != 0;
     const size_t lds3 = (nmg ? 0 : mask_bytes) + (size_t)h_slots * 8 + 256;
-    if (lds3 > (size_t)LDS_BUDGET) {
-        nmg = true;
-    }
     const uint32_t stride = (uint32_t)tile * 2u * (uint32_t)max_path_len;
     // slabs of tiles: the window lists of a slab stay below GFAL_SCAN3_LIST_MB (worst case:
     // every window of every path its own entry; what is touched is what exists)
@@ -5565,16 +5643,36 @@ static int launch_scan3(gfal_scorer *s, hipStream_t st, const Items &items, cons
     const size_t per_tile = (size_t)n_segs * stride * sizeof(uint2);
     const int slab_tiles = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_tiles, list_limit / std::max<size_t>(per_tile, 1)));
     {
-        const size_t want_masks = (size_t)slab_tiles * L.v2, want_hdr = (size_t)slab_tiles * n_segs * T3_HDR_WORDS,
-                     want_list = (size_t)slab_tiles * n_segs * stride;
-        if (want_masks > s->tile_masks_cap || want_hdr > s->t3_hdr_cap || want_list > s->t3_list_cap) {
+        const size_t want_masks = (size_t)slab_tiles * v2p, want_hdr = (size_t)slab_tiles * n_segs * T3_HDR_WORDS,
+                     want_list = (size_t)slab_tiles * n_segs * stride, want_thdr = (size_t)slab_tiles * T3_THDR_WORDS;
+        if (want_masks > s->tile_masks_cap || want_hdr > s->t3_hdr_cap || want_list > s->t3_list_cap ||
+            want_thdr > s->tile_hdr_cap || !s->d_cold) {
             if (s->have_last) HIP_TRY(hipStreamSynchronize(s->last_stream));
             int rc;
             if ((rc = dev_reserve(&s->d_tile_masks, &s->tile_masks_cap, want_masks))) return rc;
             if ((rc = dev_reserve(&s->d_t3_hdr, &s->t3_hdr_cap, want_hdr))) return rc;
             if ((rc = dev_reserve(&s->d_t3_list, &s->t3_list_cap, want_list))) return rc;
+            if ((rc = dev_reserve(&s->d_tile_hdr, &s->tile_hdr_cap, want_thdr))) return rc;
+            if (!s->d_cold) {
+                HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_cold), sizeof(Scan3Cold)));
+                HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s->h_cold), COLD_RING * sizeof(Scan3Cold),
+                                      hipHostMallocDefault));
+            }
         }
     }
+    // the cold arguments: through pinned memory (a ring: calls may be queued), copied on the
+    // device by the first kernel
+    Scan3Cold *cold = s->h_cold + (s->cold_next++ % COLD_RING);
+    cold->item_steps = items.steps;
+    cold->images = s->d_images;
+    cold->L = L;
+    cold->n_paths = n_paths;
+    cold->worklist = s->d_worklist;
+    cold->wl_count = wl_count;
+    cold->wl_capacity = s->wl_capacity;
+    cold->wl_hist = d_hist;
+    cold->status = s->d_status;
+
     TileArgs ta;
     ta.items = items;
     ta.ct = ContentTable{s->d_ct_rec, s->ct_mask};
@@ -5586,33 +5684,31 @@ static int launch_scan3(gfal_scorer *s, hipStream_t st, const Items &items, cons
     ta.segs = s->d_segs;
     ta.n_segs = n_segs;
     ta.cap = h_slots / 2;
+    ta.filter = filter ? 1 : 0;
+    ta.v2p = v2p;
+    ta.tile_hdr = s->d_tile_hdr;
     ta.tile_masks = s->d_tile_masks;
     ta.hdr = s->d_t3_hdr;
     ta.list = s->d_t3_list;
     ta.stride = stride;
 
     Scan3Args a3;
-    a3.items = items;
-    a3.item_key = s->d_item_key;
-    a3.npairs = s->d_item_npairs;
-    a3.images = s->d_images;
-    a3.L = L;
+    a3.rec3 = s->d_rec3;
+    a3.common = items.common;
+    a3.cold = s->d_cold;
     a3.tile_masks = s->d_tile_masks;
+    a3.tile_hdr = s->d_tile_hdr;
     a3.hdr = s->d_t3_hdr;
     a3.list = s->d_t3_list;
     a3.stride = stride;
     a3.n_paths = n_paths;
     a3.tile = tile;
-    a3.filter = filter ? 1 : 0;
     a3.debug = getenv("GFAL_DEBUG_SCAN2") ? atoi(getenv("GFAL_DEBUG_SCAN2")) : 0;
+    a3.v2p = v2p;
+    a3.nm_shift = s->np_scaled ? 0 : 2;
     a3.n_segs_total = n_segs;
     a3.h_slots = h_slots;
     a3.counts = d_counts;
-    a3.worklist = s->d_worklist;
-    a3.wl_count = wl_count;
-    a3.wl_capacity = s->wl_capacity;
-    a3.wl_hist = d_hist;
-    a3.status = s->d_status;
     // chunks per segment: in proportion to the segment's items (see k_scan2's launch)
     int y_want = (want_groups + n_tiles - 1) / n_tiles;
     int min_items = 24 * SCAN2_WAVES;
@@ -5632,14 +5728,16 @@ static int launch_scan3(gfal_scorer *s, hipStream_t st, const Items &items, cons
     for (int t0 = 0; t0 < n_tiles; t0 += slab_tiles) {
         const int nt = std::min(slab_tiles, n_tiles - t0);
         ta.tile0 = t0;
-        hipLaunchKernelGGL(k_tile_masks, dim3((unsigned)nt), dim3(1024), mask_bytes, st, ta);
+        hipLaunchKernelGGL(k_tile_masks, dim3((unsigned)nt), dim3(1024), mask_bytes, st, ta,
+                           (const Scan3Cold *)cold, t0 == 0 ? s->d_cold : (Scan3Cold *)nullptr,
+                           (int)sizeof(Scan3Cold));
         hipLaunchKernelGGL(k_tile, dim3((unsigned)nt, (unsigned)n_segs), dim3(1024), (size_t)T3_TILE_LDS, st, ta);
         HIP_TRY(hipGetLastError());
         a3.tile0 = t0;
         a3.n_tiles = nt;
         for (int s0 = 0; s0 < n_segs; s0 += MAX_SEGS) {
             const int ns = std::min(MAX_SEGS, n_segs - s0);
-            a3.segs = s->d_segs + s0;
+            a3.segs = s->d_segs3 + s0;
             a3.n_segs = ns;
             a3.seg0 = s0;
             unsigned y_total = 0;
@@ -6216,20 +6314,18 @@ static int build_content_table(gfal_scorer *s)
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_ct_hash), (size_t)slots_pow2 * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_ct_mult), (size_t)slots_pow2 * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_ct_rec), (size_t)slots_pow2 * sizeof(uint4)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_item_key), std::max<size_t>(n_slots, 1) * sizeof(uint32_t)));
     hipStream_t st = s->stream;
     HIP_TRY(hipMemsetAsync(s->d_ct_key, 0xFF, (size_t)slots_pow2 * sizeof(uint32_t), st));
     HIP_TRY(hipMemsetAsync(s->d_ct_hash, 0, (size_t)slots_pow2 * sizeof(uint32_t), st));
     HIP_TRY(hipMemsetAsync(s->d_ct_mult, 0, (size_t)slots_pow2 * sizeof(uint32_t), st));
     HIP_TRY(hipMemsetAsync(s->d_ct_rec, 0xFF, (size_t)slots_pow2 * sizeof(uint4), st));
-    HIP_TRY(hipMemsetAsync(s->d_item_key, 0xFF, std::max<size_t>(n_slots, 1) * sizeof(uint32_t), st));
     if (n_slots > 0) {
         const Items items{s->d_item_steps, s->d_item_base, s->d_item_len, s->d_item_pairs,
                           s->d_item_pbase, s->n_items, s->d_item_common, s->d_item_hdr, s->d_item_weight};
         const unsigned blocks = (n_slots + 255u) / 256u;
         hipLaunchKernelGGL(k_ct_build, dim3(blocks), dim3(256), 0, st, items, s->d_slot_orig, n_slots,
                            s->d_item_hash, s->d_ct_key, s->d_ct_hash, s->d_ct_mult, s->ct_mask, s->d_ct_rec,
-                           s->d_item_key);
+                           s->d_rec3, s->d_item_r3);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipStreamSynchronize(st));
