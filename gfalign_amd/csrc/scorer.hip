@@ -1169,16 +1169,16 @@ constexpr int MAX_SEGS = 64;              // length segments per launch (one lan
 constexpr uint32_t H_FP_SHIFT = 14;       // entry: fp[31:14] | index of the window's first step in the staged steps [13:0]
 constexpr uint32_t NOT_A0 = 0x80000000u;  // node mask bit 31: node is NOT the tile's first node
 
-__host__ __device__ __forceinline__ uint32_t whash_init(int M)
-{
-    return 0x811C9DC5u ^ ((uint32_t)M * 0x9E3779B1u);
-}
+// (the length goes in at the end: the hashes of all the windows that start at one
+// position are prefixes of one fold -- k_tile)
+__host__ __device__ __forceinline__ uint32_t whash_init() { return 0x811C9DC5u; }
 __host__ __device__ __forceinline__ uint32_t whash_step(uint32_t h, uint32_t code)
 {
     return (h ^ code) * 0x01000193u;
 }
-__host__ __device__ __forceinline__ uint32_t whash_final(uint32_t h)
+__host__ __device__ __forceinline__ uint32_t whash_final(uint32_t h, int M)
 {
+    h ^= (uint32_t)M * 0x9E3779B1u;
     h ^= h >> 16;
     h *= 0x7FEB352Du;
     h ^= h >> 15;
@@ -1411,7 +1411,7 @@ __device__ __forceinline__ void insert_windows(uint16_t *steps, int nm, uint32_t
         if (p == base)
             for (int t = pass_lo; t < pass_hi; ++t)
                 bits |= (t != base && x + M <= (int)lcp_all[t]) ? (1u << t) : 0u;
-        uint32_t h = whash_init(M);
+        uint32_t h = whash_init();
         bool real = true;
         for (int k = 0; k < P0; ++k) {
             const uint32_t d = window_pair(step32, idx, k);
@@ -1424,7 +1424,7 @@ __device__ __forceinline__ void insert_windows(uint16_t *steps, int nm, uint32_t
             }
         }
         if (!real) continue;
-        h = whash_final(h);
+        h = whash_final(h, M);
         const uint32_t want = (h & ~((1u << H_FP_SHIFT) - 1u)) | idx;
         uint32_t slot = h & (H_SLOTS - 1u);
         const uint32_t stride = ((h >> H_LOG_S) & (H_SLOTS - 1u)) | 1u;
@@ -3343,7 +3343,7 @@ __global__ __launch_bounds__(CHILD_THREADS) void k_child(ChildArgs a)
     if (chunk == 0 && s != STEP_NOMATCH) {
         const uint16_t *step = img + a.L.step_at();
         for (int M = lmax + 1 + tid; M <= cap; M += CHILD_THREADS) {
-            uint32_t hf = whash_init(M), hr = whash_init(M);
+            uint32_t hf = whash_init(), hr = whash_init();
             bool ok = true, pal = true;
             for (int t = 0; t < M; ++t) {
                 const uint32_t cf = stepA(n - M + t);
@@ -3354,8 +3354,8 @@ __global__ __launch_bounds__(CHILD_THREADS) void k_child(ChildArgs a)
                 hr = whash_step(hr, cr);
             }
             if (!ok) continue;
-            hits += ct_lookup(a, whash_final(hf), M, step, n - M, 1, 0u);
-            if (!pal) hits += ct_lookup(a, whash_final(hr), M, step, n - 1, -1, 1u);
+            hits += ct_lookup(a, whash_final(hf, M), M, step, n - M, 1, 0u);
+            if (!pal) hits += ct_lookup(a, whash_final(hr, M), M, step, n - 1, -1, 1u);
         }
     }
 
@@ -3687,10 +3687,7 @@ __global__ __launch_bounds__(256) void k_store_paths(const int32_t *__restrict__
 // compared with the entry's, and the LDS probe compares full 32-bit indices.
 // --------------------------------------------------------------------------
 constexpr int T3_MAX = 31;                 // tile paths: bits 0..30 of a node mask (bit 31: NOT_A0)
-constexpr int HT_LOG = 13;
-constexpr int HT_SLOTS = 1 << HT_LOG;      // k_tile's own table (dedup of the tile's windows)
 constexpr uint32_t KEY_EMPTY = 0xFFFFFFFFu;
-constexpr int T3_HDR_WORDS = 96;           // per (tile, length): n_passes, then {t0 | t1 << 8, begin, count} per pass
 constexpr int T3_THDR_WORDS = 128;         // per tile: 32 lengths | 32 first steps | 32 common prefixes with path 0
 constexpr int T3_CT_INLINE = 5;            // steps of an alignment a content-table record carries
 
@@ -3708,12 +3705,18 @@ struct TileArgs {
     int n_paths, tile, tile0;      // tile0: first tile of this launch (slab)
     const LenSeg *segs;
     int n_segs;
-    uint32_t cap;                  // entries one k_scan3 pass holds (half its table)
+    int debug;                     // GFAL_DEBUG_TILE: stop k_tile after phase 1 (A) / 2 (R); 3: first path's windows only; 4: up to 5 steps only (timing probes)
     int filter, v2p;               // v2p: mask words per tile = v2 + 2 (word v2 stays zero: padding lanes point at it)
     uint32_t *tile_hdr;            // [tiles of the slab][T3_THDR_WORDS]
     uint32_t *tile_masks;          // [tiles of the slab][v2p]
-    uint32_t *hdr;                 // [tiles of the slab][n_segs][T3_HDR_WORDS]
-    uint2 *list;                   // [tiles of the slab][n_segs][stride]
+    // reference: the content indices of every window (<= T3_REG_M steps) of the batch's longest
+    // path (image slot 0), [n_segs][2 strands][L.nm], KEY_EMPTY = no alignment has that content.
+    // A tile whose first path agrees with the reference over a window copies the index
+    // (coalesced) instead of probing the content table (one scattered line per probe).
+    uint32_t *ref;
+    int n_launch_tiles;            // k_tile_masks: blocks beyond this many fill `ref`
+    uint32_t *list_count;          // [tiles of the slab][n_segs] entries of every list
+    uint2 *list;                   // [tiles of the slab][n_segs][stride] {content index, tile paths}
     uint32_t stride;
 };
 
@@ -3724,11 +3727,16 @@ struct TileArgs {
 // NOT_A0 (every open pair takes the overhang test).  Also the tile's header (lengths,
 // first steps) and -- block 0 -- the cold arguments of k_scan3.
 struct Scan3Cold;
+__device__ void t3_ref_block(const TileArgs &a, int block, int tid);
 __global__ __launch_bounds__(1024) void k_tile_masks(TileArgs a, const Scan3Cold *cold_src, Scan3Cold *cold_dst,
                                                      int cold_bytes)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds32[];
     const int tid = threadIdx.x;
+    if ((int)blockIdx.x >= a.n_launch_tiles) {       // the reference blocks
+        t3_ref_block(a, (int)blockIdx.x - a.n_launch_tiles, tid);
+        return;
+    }
     if (blockIdx.x == 0 && cold_dst)
         for (int i = tid; i < cold_bytes / 4; i += 1024)
             reinterpret_cast<uint32_t *>(cold_dst)[i] = reinterpret_cast<const uint32_t *>(cold_src)[i];
@@ -3792,257 +3800,457 @@ __global__ __launch_bounds__(1024) void k_tile_masks(TileArgs a, const Scan3Cold
     if (tid < 2) dst[v2 + tid] = 0;
 }
 
-// index of the content  W[k] = F[dir * k] ^ flip  (k < M) in the content table, or
-// KEY_EMPTY.  w0..w4: its first steps (0xFFFFFFFF beyond M), already in registers.
-__device__ __forceinline__ uint32_t ct_find(const TileArgs &a, uint32_t h, int M, const uint16_t *F,
-                                            int dir, uint32_t flip, const uint32_t (&w)[T3_CT_INLINE])
+// does the record r hold the content  W[k] = F[dir * k] ^ flip  (k < M)?  w: its first steps.
+__device__ __forceinline__ bool ct_match(const TileArgs &a, const uint4 &r, int M, const uint16_t *F, int dir,
+                                         uint32_t flip, const uint32_t (&w)[T3_CT_INLINE])
 {
-    uint32_t idx = h & a.ct.mask;
-    while (true) {
-        const uint4 r = a.ct.rec[idx];
-        if (r.x == CT_EMPTY) return KEY_EMPTY;
-        if ((int)(r.y & 0xFFFFu) == M) {
-            bool eq = (r.y >> 16) == w[0];
-            if (M > 1) eq &= (r.z & 0xFFFFu) == w[1];
-            if (M > 2) eq &= (r.z >> 16) == w[2];
-            if (M > 3) eq &= (r.w & 0xFFFFu) == w[3];
-            if (M > 4) eq &= (r.w >> 16) == w[4];
-            if (eq && M > T3_CT_INLINE) {
-                const uint32_t it = r.x >> 6;
-                const uint16_t *bp = a.items.steps + (size_t)a.items.base[it] * WAVE + (r.x & 63u);
-                for (int k = T3_CT_INLINE; k < M; ++k)
-                    eq &= (uint32_t)bp[(size_t)k * WAVE] == ((uint32_t)F[dir * k] ^ flip);
-            }
-            if (eq) return idx;
-        }
-        idx = (idx + 1u) & a.ct.mask;
+    if ((int)(r.y & 0xFFFFu) != M) return false;
+    bool eq = (r.y >> 16) == w[0];
+    if (M > 1) eq &= (r.z & 0xFFFFu) == w[1];
+    if (M > 2) eq &= (r.z >> 16) == w[2];
+    if (M > 3) eq &= (r.w & 0xFFFFu) == w[3];
+    if (M > 4) eq &= (r.w >> 16) == w[4];
+    if (eq && M > T3_CT_INLINE) {
+        const uint32_t it = r.x >> 6;
+        const uint16_t *bp = a.items.steps + (size_t)a.items.base[it] * WAVE + (r.x & 63u);
+        for (int k = T3_CT_INLINE; k < M; ++k)
+            eq &= (uint32_t)bp[(size_t)k * WAVE] == ((uint32_t)F[dir * k] ^ flip);
     }
+    return eq;
 }
 
-// {key, mask} table in LDS, linear probing; misc[0] counts the entries
-__device__ __forceinline__ void t3_insert(uint32_t *tab, uint32_t *misc, uint32_t key, uint32_t bits,
-                                          uint32_t cap)
+// Append v to a window list for the lanes that `have` one: one LDS atomic per wave (1024
+// threads adding to one counter lane by lane serialise).  May be called in divergent code.
+__device__ __forceinline__ void t3_append(uint32_t *counter, uint2 *out, bool have, uint2 v)
 {
-    uint32_t slot = key & (HT_SLOTS - 1u);
-    while (true) {
-        const uint32_t old = atomicCAS(&tab[2u * slot], KEY_EMPTY, key);
-        if (old == KEY_EMPTY) {
-            if (atomicAdd(&misc[0], 1u) + 1u > cap) misc[1] = 1u;
+    const lanemask m = WAVE_MASK(have);
+    if (m == 0) return;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int leader = __builtin_ctzll(m);
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+    if (have) out[base + lanes_below(m, lane)] = v;
+}
+
+// One window's two lookups (forward content, reverse complement) on their way through
+// the content table: issue() sends the first probes, resolve() follows them up and
+// appends {content index, tile paths} to the list of the window's length.
+struct T3Pend {
+    uint4 rf, rr;
+    uint32_t xf, xr, bits;
+    int seg, M;      // M == 0: nothing pending
+};
+
+__device__ __forceinline__ void t3_issue(const TileArgs &a, T3Pend &p, uint32_t hf, uint32_t hr)
+{
+    p.xf = hf & a.ct.mask;
+    p.xr = hr & a.ct.mask;
+    p.rf = a.ct.rec[p.xf];
+    p.rr = a.ct.rec[p.xr];
+}
+
+__device__ __forceinline__ void t3_resolve(const TileArgs &a, T3Pend &p, const uint16_t *F,
+                                           const uint32_t (&wf)[T3_CT_INLINE], const uint32_t (&wr)[T3_CT_INLINE],
+                                           uint32_t *cnt, uint2 *lists)
+{
+    const int M = p.M;
+    uint32_t kf = KEY_EMPTY, kr = KEY_EMPTY;
+    while (p.rf.x != CT_EMPTY) {
+        if (ct_match(a, p.rf, M, F, 1, 0u, wf)) {
+            kf = p.xf;
             break;
         }
-        if (old == key) break;
-        slot = (slot + 1u) & (HT_SLOTS - 1u);
+        p.xf = (p.xf + 1u) & a.ct.mask;
+        p.rf = a.ct.rec[p.xf];
     }
-    atomicOr(&tab[2u * slot + 1u], bits);
+    while (p.rr.x != CT_EMPTY) {
+        if (ct_match(a, p.rr, M, F + (M - 1), -1, 1u, wr)) {
+            kr = p.xr;
+            break;
+        }
+        p.xr = (p.xr + 1u) & a.ct.mask;
+        p.rr = a.ct.rec[p.xr];
+    }
+    // (p.seg is the same for every lane that is here with this slot?  Not necessarily:
+    // lanes fill their slots at different segments -- so one append per distinct segment)
+    lanemask todo = WAVE_MASK(true);
+    while (todo) {
+        const int seg = __builtin_amdgcn_readlane(p.seg, __builtin_ctzll(todo));
+        const bool mine = p.seg == seg;
+        uint2 *out = lists + (size_t)seg * a.stride;
+        t3_append(&cnt[seg], out, mine && kf != KEY_EMPTY, make_uint2(kf, p.bits));
+        t3_append(&cnt[seg], out, mine && kr != KEY_EMPTY && kr != kf, make_uint2(kr, p.bits));
+        todo &= ~WAVE_MASK(mine);
+    }
+    p.M = 0;
 }
 
-// the windows (forward start f, M steps) of one tile path, both strands -> the table
-__device__ __forceinline__ void t3_window(const TileArgs &a, uint32_t *tab, uint32_t *misc,
-                                          const uint16_t *Fp, int f, int M, uint32_t bits)
+constexpr int T3_REG_M = 16;         // windows of up to 16 steps are hashed from registers
+constexpr int T3_RUN_CAP = 127;      // run[][]: positions two paths agree on from here, capped
+constexpr int T3_PEND = 3;           // windows of one thread in flight (two lookups each)
+constexpr int T3_WL_CAP = 4096;      // (path, position) pairs with windows of their own, gathered in LDS
+
+// tile paths t with run[f][t] >= M, from the 32 run bytes of position f (eight dwords)
+__device__ __forceinline__ uint32_t t3_share_bits(const uint32_t (&r)[8], int M)
+{
+    uint32_t bits = 0;
+    const uint32_t m4 = (uint32_t)M * 0x01010101u;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+        const uint32_t ge = (((r[d] | 0x80808080u) - m4) & 0x80808080u) >> 7;     // bit 8 i: byte i >= M
+        bits |= ((ge * 0x00204081u) >> 21 & 0xFu) << (4 * d);
+    }
+    return bits & 0x7FFFFFFFu;       // (byte 31 is the run against the reference path, not a tile path)
+}
+
+// the first T3_REG_M steps from F (path of n steps, position f) and how many of them can
+// match something
+__device__ __forceinline__ int t3_load_steps(const uint16_t *F, int f, int n, uint32_t (&c)[T3_REG_M])
+{
+#pragma unroll
+    for (int k = 0; k < T3_REG_M; ++k) c[k] = f + k < n ? (uint32_t)F[k] : 0xFFFFu;
+    int m_real = T3_REG_M;
+#pragma unroll
+    for (int k = T3_REG_M - 1; k >= 0; --k)
+        if (c[k] >= STEP_NOMATCH) m_real = k;
+    return m_real;
+}
+
+// hash of the reverse complement of the first M of the steps c
+__device__ __forceinline__ uint32_t t3_hash_rc(const uint32_t (&c)[T3_REG_M], int M)
+{
+    uint32_t hr = whash_init();
+#pragma unroll
+    for (int k = T3_REG_M - 1; k >= 0; --k)
+        if (k < M) hr = whash_step(hr, c[k] ^ 1u);
+    return whash_final(hr, M);
+}
+
+// the first steps of the M-step window c and of its reverse complement (ct_match)
+__device__ __forceinline__ void t3_first_steps(const uint32_t (&c)[T3_REG_M], int M,
+                                               uint32_t (&wf)[T3_CT_INLINE], uint32_t (&wr)[T3_CT_INLINE])
+{
+#pragma unroll
+    for (int j = 0; j < T3_CT_INLINE; ++j) {
+        wf[j] = j < M ? c[j] : 0xFFFFFFFFu;
+        wr[j] = 0xFFFFFFFFu;
+#pragma unroll
+        for (int k = 0; k < T3_REG_M; ++k)
+            if (k == M - 1 - j) wr[j] = c[k] ^ 1u;
+    }
+}
+
+// All windows that start at position f of one tile path, every length of the scorer's
+// segments: hashed, looked up (or copied from the reference), appended.  min_m: lengths up
+// to min_m - 1 are someone else's (the window is shared with the tile's first path);
+// own_bits: the bits to enter, or 0 = this IS the first path, enter every path that shares
+// the window (run row of f).
+__device__ __forceinline__ void t3_windows_at(const TileArgs &a, const uint16_t *Fp, int f, int n, int min_m,
+                                              uint32_t own_bits, const uint8_t *run, const uint32_t *segm,
+                                              uint32_t *cnt, uint2 *lists)
 {
     const uint16_t *F = Fp + f;
-    uint32_t hf = whash_init(M), hr = hf;
-    uint32_t wf[T3_CT_INLINE], wr[T3_CT_INLINE];
+    uint32_t c[T3_REG_M];
+    const int m_real = t3_load_steps(F, f, n, c);
+    uint32_t r8[8];
+    int run_ref = 0;                     // the first path agrees with the reference this far from f on
+    if (own_bits == 0u) {
+        const uint4 *row = reinterpret_cast<const uint4 *>(run + (size_t)f * 32);
+        const uint4 lo = row[0], hi = row[1];
+        r8[0] = lo.x, r8[1] = lo.y, r8[2] = lo.z, r8[3] = lo.w;
+        r8[4] = hi.x, r8[5] = hi.y, r8[6] = hi.z, r8[7] = hi.w;
+        run_ref = (int)(hi.w >> 24);
+    }
+    T3Pend pend[T3_PEND];
 #pragma unroll
-    for (int k = 0; k < T3_CT_INLINE; ++k) wf[k] = wr[k] = 0xFFFFFFFFu;
-    bool real = true;
-    for (int k = 0; k < M; ++k) {
-        const uint32_t c = F[k], d = (uint32_t)F[M - 1 - k] ^ 1u;
-        real &= c < STEP_NOMATCH;            // a step that equals nothing: no alignment matches
-        hf = whash_step(hf, c);
-        hr = whash_step(hr, d);
+    for (int g = 0; g < T3_PEND; ++g) pend[g].M = 0;
+    uint32_t hf = whash_init();
+    int k_done = 0, n_pend = 0;
+    for (int s = 0; s < a.n_segs; ++s) {
+        const int M = (int)segm[s];            // (uniform)
+        if (M > T3_REG_M) continue;            // (the long ones: below)
+        if (a.debug == 4 && M > T3_CT_INLINE) continue;
+        if (M < k_done) {                      // (lengths ascend inside a run of segments)
+            hf = whash_init();
+            k_done = 0;
+        }
 #pragma unroll
-        for (int j = 0; j < T3_CT_INLINE; ++j)
-            if (k == j) {
-                wf[j] = c;
-                wr[j] = d;
+        for (int k = 0; k < T3_REG_M; ++k)
+            if (k >= k_done && k < M) hf = whash_step(hf, c[k]);
+        k_done = M;
+        if (M > m_real || M < min_m) continue;
+        const uint32_t bits = own_bits ? own_bits : t3_share_bits(r8, M);
+        if (run_ref >= M) {                    // the reference path's window: its indices
+            const uint32_t kf = a.ref[((size_t)s * 2) * a.L.nm + f], kr = a.ref[((size_t)s * 2 + 1) * a.L.nm + f];
+            uint2 *out = lists + (size_t)s * a.stride;
+            t3_append(&cnt[s], out, kf != KEY_EMPTY, make_uint2(kf, bits));
+            t3_append(&cnt[s], out, kr != KEY_EMPTY && kr != kf, make_uint2(kr, bits));
+            continue;
+        }
+        // (a slot of the in-flight set; the set is resolved when it is full)
+#pragma unroll
+        for (int g = 0; g < T3_PEND; ++g)
+            if (g == n_pend) {
+                T3Pend &p = pend[g];
+                p.M = M;
+                p.seg = s;
+                p.bits = bits;
+                t3_issue(a, p, whash_final(hf, M), t3_hash_rc(c, M));
             }
+        if (++n_pend == T3_PEND) {
+#pragma unroll
+            for (int g = 0; g < T3_PEND; ++g) {
+                uint32_t wf[T3_CT_INLINE], wr[T3_CT_INLINE];
+                t3_first_steps(c, pend[g].M, wf, wr);
+                t3_resolve(a, pend[g], F, wf, wr, cnt, lists);
+            }
+            n_pend = 0;
+        }
     }
-    if (!real) return;
-    const uint32_t kf = ct_find(a, whash_final(hf), M, F, 1, 0u, wf);
-    if (kf != KEY_EMPTY) t3_insert(tab, misc, kf, bits, a.cap);
-    const uint32_t kr = ct_find(a, whash_final(hr), M, F + (M - 1), -1, 1u, wr);
-    if (kr != KEY_EMPTY && kr != kf) t3_insert(tab, misc, kr, bits, a.cap);
-}
-
-// the entries whose mask meets `range` -> out[0 ..), masks cut to the range; returns the
-// count (all threads).  misc[2]: cursor.
-__device__ __forceinline__ uint32_t t3_emit(const uint32_t *tab, uint32_t *misc, uint32_t range,
-                                            uint2 *out, int tid)
-{
-    __syncthreads();
-    if (tid == 0) misc[2] = 0;
-    __syncthreads();
-    const int lane = tid & (WAVE - 1);
-    for (int s0 = 0; s0 < HT_SLOTS; s0 += 1024) {
-        const uint32_t key = tab[2 * (s0 + tid)], m = tab[2 * (s0 + tid) + 1] & range;
-        const bool have = key != KEY_EMPTY && m != 0u;
-        const lanemask bm = WAVE_MASK(have);
-        if (bm == 0) continue;
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&misc[2], (uint32_t)__popcll(bm));
-        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-        if (have) out[base + lanes_below(bm, lane)] = make_uint2(key, m);
+#pragma unroll
+    for (int g = 0; g < T3_PEND; ++g)
+        if (g < n_pend) {
+            uint32_t wf[T3_CT_INLINE], wr[T3_CT_INLINE];
+            t3_first_steps(c, pend[g].M, wf, wr);
+            t3_resolve(a, pend[g], F, wf, wr, cnt, lists);
+        }
+    // alignments of more than T3_REG_M steps: hashed from memory, one at a time
+    for (int s = 0; s < a.n_segs; ++s) {
+        const int M = (int)segm[s];
+        if (M <= T3_REG_M || f + M > n || M < min_m) continue;
+        uint32_t h1 = whash_init(), h2 = h1;
+        bool real = true;
+        for (int k = 0; k < M; ++k) {
+            const uint32_t x = F[k], y = (uint32_t)F[M - 1 - k] ^ 1u;
+            real &= x < STEP_NOMATCH;
+            h1 = whash_step(h1, x);
+            h2 = whash_step(h2, y);
+        }
+        if (!real) continue;
+        T3Pend p;
+        p.M = M;
+        p.seg = s;
+        if (own_bits) {
+            p.bits = own_bits;
+        } else {
+            p.bits = 0;
+            if (M <= T3_RUN_CAP) {
+                for (int t = 0; t < T3_MAX; ++t) p.bits |= (int)run[(size_t)f * 32 + t] >= M ? (1u << t) : 0u;
+            } else {
+                p.bits = 1u;       // (longer than a run is ever counted: every path enters its own)
+            }
+        }
+        uint32_t wf[T3_CT_INLINE], wr[T3_CT_INLINE];
+#pragma unroll
+        for (int j = 0; j < T3_CT_INLINE; ++j) {
+            wf[j] = F[j];
+            wr[j] = (uint32_t)F[M - 1 - j] ^ 1u;
+        }
+        t3_issue(a, p, whash_final(h1, M), whash_final(h2, M));
+        t3_resolve(a, p, F, wf, wr, cnt, lists);
     }
-    __syncthreads();
-    return misc[2];
 }
 
-__device__ __forceinline__ void t3_clear(uint32_t *tab, uint32_t *misc, int tid)
+// The reference (TileArgs::ref), filled by extra blocks of k_tile_masks: thread = (position
+// f of the batch's longest path, one length): two lookups.
+__device__ void t3_ref_block(const TileArgs &a, int block, int tid)
 {
-    uint4 *t4 = reinterpret_cast<uint4 *>(tab);
-    for (int i = tid; i < HT_SLOTS / 2; i += 1024) t4[i] = make_uint4(KEY_EMPTY, 0u, KEY_EMPTY, 0u);
-    if (tid < 4) misc[tid] = 0;
+    const int n_r = a.images[a.L.len_at()];
+    const uint16_t *Fr = a.images + a.L.step_at();
+    const int w = block * 1024 + tid;
+    const int s = w / a.L.nm, f = w % a.L.nm;
+    if (s >= a.n_segs) return;
+    const int M = (int)a.segs[s].m;
+    uint32_t kf = KEY_EMPTY, kr = KEY_EMPTY;
+    if (M <= T3_REG_M && f + M <= n_r) {
+        uint32_t c[T3_REG_M];
+        const int m_real = t3_load_steps(Fr + f, f, n_r, c);
+        if (M <= m_real) {
+            uint32_t hf = whash_init();
+#pragma unroll
+            for (int k = 0; k < T3_REG_M; ++k)
+                if (k < M) hf = whash_step(hf, c[k]);
+            T3Pend p;
+            p.M = M;
+            t3_issue(a, p, whash_final(hf, M), t3_hash_rc(c, M));
+            uint32_t wf[T3_CT_INLINE], wr[T3_CT_INLINE];
+            t3_first_steps(c, M, wf, wr);
+            while (p.rf.x != CT_EMPTY) {
+                if (ct_match(a, p.rf, M, Fr + f, 1, 0u, wf)) {
+                    kf = p.xf;
+                    break;
+                }
+                p.xf = (p.xf + 1u) & a.ct.mask;
+                p.rf = a.ct.rec[p.xf];
+            }
+            while (p.rr.x != CT_EMPTY) {
+                if (ct_match(a, p.rr, M, Fr + f + (M - 1), -1, 1u, wr)) {
+                    kr = p.xr;
+                    break;
+                }
+                p.xr = (p.xr + 1u) & a.ct.mask;
+                p.rr = a.ct.rec[p.xr];
+            }
+        }
+    }
+    a.ref[((size_t)s * 2) * a.L.nm + f] = kf;
+    a.ref[((size_t)s * 2 + 1) * a.L.nm + f] = kr;
 }
 
-constexpr int T3_TILE_LDS = (2 * HT_SLOTS + 3 * 1024 + 32 + 16) * 4;
+__host__ __device__ inline size_t t3_tile_lds(int n_segs)
+{
+    return (size_t)(1024 + 8192 + T3_WL_CAP + 32 + 16 + 2 * ((n_segs + 3) & ~3)) * 4;
+}
 
-__global__ __launch_bounds__(1024, 8) void k_tile(TileArgs a)
+// One workgroup per tile.  Per (tile, length) the list of {content index, tile paths}
+// k_scan3 enters into its table: one entry per window of the tile's first path (with the
+// paths that share it) and per window another path has of its own; identical contents
+// may appear more than once (k_scan3's insert merges them).
+__global__ __launch_bounds__(1024) void k_tile(TileArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds32[];
-    uint32_t *tab = lds32;                       // [HT_SLOTS] {key, mask}
-    uint32_t *eqbm = tab + 2 * HT_SLOTS;         // [32][32] bit f of row t: step f of path t == step f of the base path
-    uint32_t *shm = eqbm + 1024;                 // [32][32] bit i of [t][j]: window 32 j + i of path t is the base path's
-    uint32_t *wbits = shm + 1024;                // [1024] per window of the base path: the tile paths that share it
-    uint32_t *nlen = wbits + 1024;               // [32]
-    uint32_t *misc = nlen + 32;                  // [0] entries [1] overflow [2] emit cursor
+    uint32_t *eqbm = lds32;                      // [32 words][32 paths] bit f of (f / 32, t): step f of path t == step f of path 0
+    uint8_t *run = reinterpret_cast<uint8_t *>(eqbm + 1024);      // [1024][32] run[f][t]: positions from f on where path t agrees
+    uint32_t *wl = eqbm + 1024 + 8192;           // [T3_WL_CAP] path | position << 8
+    uint32_t *nlen = wl + T3_WL_CAP;             // [32] ([31]: the reference path)
+    uint32_t *misc = nlen + 32;                  // [16] [0]: work-list entries
+    uint32_t *cnt = misc + 16;                   // [n_segs] entries per list
+    uint32_t *segm = cnt + ((a.n_segs + 3) & ~3);                 // [n_segs] the lengths
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tile_rel = (int)blockIdx.x;
     const int path0 = (a.tile0 + tile_rel) * a.tile;
     const int T = min(a.tile, a.n_paths - path0);
-    const LenSeg sg = a.segs[blockIdx.y];
-    const int M = (int)sg.m;
-    uint32_t *hdr = a.hdr + ((size_t)tile_rel * a.n_segs + blockIdx.y) * T3_HDR_WORDS;
-    uint2 *out = a.list + ((size_t)tile_rel * a.n_segs + blockIdx.y) * a.stride;
+    uint2 *lists = a.list + (size_t)tile_rel * a.n_segs * a.stride;
     const size_t img_stride = (size_t)a.L.total;
     const uint16_t *img0 = a.images + (size_t)path0 * img_stride;
 
-    if (tid < 32) nlen[tid] = tid < T ? (uint32_t)img0[(size_t)tid * img_stride + a.L.len_at()] : 0u;
-    t3_clear(tab, misc, tid);
-    __syncthreads();
-    int base = -1;
-    for (int t = 0; t < T; ++t)
-        if (base < 0 && (int)nlen[t] >= M) base = t;
-    if (base < 0) {                              // no tile path has an M-step window
-        if (tid == 0) {
-            hdr[0] = 1;
-            hdr[1] = (uint32_t)T << 8;
-            hdr[2] = 0;
-            hdr[3] = 0;
-        }
-        return;
+    if (tid < 32) {
+        uint32_t n = 0;
+        if (tid < T) n = img0[(size_t)tid * img_stride + a.L.len_at()];
+        if (tid == 31) n = a.images[a.L.len_at()];       // the reference: image slot 0
+        nlen[tid] = n;
     }
-    const int n_b = (int)nlen[base];
-    const uint16_t *Fb = img0 + (size_t)base * img_stride + a.L.step_at();
+    if (tid < 16) misc[tid] = 0;
+    for (int s = tid; s < a.n_segs; s += 1024) {
+        cnt[s] = 0;
+        segm[s] = a.segs[s].m;
+    }
+    __syncthreads();
+    const int n_b = (int)nlen[0];
+    const uint16_t *Fb = img0 + a.L.step_at();
 
-    // (A) where every path agrees with the base path, one bit per position
-    for (int c = wave; c < T * 16; c += 1024 / WAVE) {
-        const int t = c >> 4, p = (c & 15) * WAVE + lane;
-        const int lim = min((int)nlen[t], n_b);
-        bool eq = false;
-        if (p < lim) eq = img0[(size_t)t * img_stride + a.L.step_at() + p] == Fb[p];
-        const lanemask m = WAVE_MASK(eq);
-        if (lane == 0) {
-            eqbm[t * 32 + (c & 15) * 2] = (uint32_t)m;
-            eqbm[t * 32 + (c & 15) * 2 + 1] = (uint32_t)(m >> 32);
+    // (A) where every path -- and the reference -- agrees with the tile's first path, one bit
+    // per position (a wave takes whole paths; eight blocks of 64 positions are loaded before
+    // the first is compared)
+    for (int half = 0; half < 2; ++half) {
+        if (half * 512 >= n_b && half > 0) {
+            for (int i = tid; i < 32 * 16; i += 1024) eqbm[(16 + (i & 15)) * 32 + (i >> 4)] = 0;
+            break;
         }
-    }
-    __syncthreads();
-    // (B1) thread (t, j): which of the windows 32 j .. 32 j + 31 of path t lie where it agrees
-    // with the base path (then the window IS the base path's: entered there)
-    const int q = tid >> 5, j = tid & 31;
-    {
-        uint32_t sh = 0;
-        if (q < T && q != base && (int)nlen[q] >= M) {
-            int nz = 32 * (j + 1);               // next position >= the dword's end where the paths differ
-            for (int jj = j + 1; jj < 32; ++jj) {
-                const uint32_t w = ~eqbm[q * 32 + jj];
-                if (w) {
-                    nz = 32 * jj + __builtin_ctz(w);
-                    break;
+        uint32_t vb[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int p = half * 512 + k * WAVE + lane;
+            vb[k] = p < n_b ? (uint32_t)Fb[p] : 0x20000u;      // (fillers equal nothing)
+        }
+        for (int t = wave; t < 32; t += 1024 / WAVE) {
+            const int lim = min((int)nlen[t], n_b);
+            const uint16_t *Ft = t == 31 ? a.images + a.L.step_at()
+                                         : img0 + (size_t)min(t, T - 1) * img_stride + a.L.step_at();
+            uint32_t vt[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int p = half * 512 + k * WAVE + lane;
+                vt[k] = p < lim ? (uint32_t)Ft[p] : 0x10000u;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const lanemask m = WAVE_MASK(vt[k] == vb[k]);
+                if (lane == 0) {
+                    eqbm[(half * 16 + k * 2) * 32 + t] = (uint32_t)m;
+                    eqbm[(half * 16 + k * 2 + 1) * 32 + t] = (uint32_t)(m >> 32);
                 }
-                nz = 32 * (jj + 1);
-            }
-            const uint32_t w = eqbm[q * 32 + j];
-            for (int i = 31; i >= 0; --i) {
-                if (!((w >> i) & 1u)) nz = 32 * j + i;
-                if (nz >= 32 * j + i + M) sh |= 1u << i;
             }
         }
-        shm[q * 32 + j] = sh;
     }
     __syncthreads();
-    // (B2) thread (q, j) -> window f = 32 j + q of the base path: who shares it
+    if (a.debug == 1) return;
+    // (R) thread (j, t): for the positions 32 j .. 32 j + 31 of path t, how far it goes on
+    // agreeing with the first path (a window of M steps that lies inside such a run IS the
+    // first path's window: entered there, with this path's bit).  Positions of a path
+    // that have windows of their own go to the work list.
+    int max_m = 0;
+    for (int s = 0; s < a.n_segs; ++s) max_m = max(max_m, (int)segm[s]);
+    const int q = tid & 31, j = tid >> 5;
+    int inline_from = 32;                        // (work list full: the rest is done by this thread itself)
     {
-        uint32_t bits = 1u << base;
-        for (int t = 0; t < T; ++t) bits |= ((shm[t * 32 + j] >> q) & 1u) << t;
-        wbits[32 * j + q] = bits;
-    }
-    __syncthreads();
-    // (C) the base path's windows, and of every other path those that are its own
-    {
-        const int f = 32 * j + q;
-        if (f + M <= n_b && misc[1] == 0u) t3_window(a, tab, misc, Fb, f, M, wbits[f]);
-        if (q < T && q != base && (int)nlen[q] >= M) {
-            const int n_t = (int)nlen[q];
-            const uint16_t *Fp = img0 + (size_t)q * img_stride + a.L.step_at();
-            uint32_t u = ~shm[q * 32 + j];
-            while (u) {
-                const int i = __builtin_ctz(u);
-                u &= u - 1u;
-                const int g = 32 * j + i;
-                if (g + M > n_t) break;
-                if (misc[1] != 0u) break;
-                t3_window(a, tab, misc, Fp, g, M, 1u << q);
+        int nz = 32 * (j + 1);                   // next position >= the dword's end where the paths differ
+        for (int jj = j + 1; jj < 32; ++jj) {
+            const uint32_t w = ~eqbm[jj * 32 + q];
+            if (w) {
+                nz = 32 * jj + __builtin_ctz(w);
+                break;
             }
+            nz = 32 * (jj + 1);
+        }
+        const uint32_t w = eqbm[j * 32 + q];
+        const int n_t = (q >= 1 && q < T) ? (int)nlen[q] : 0;
+        uint32_t own = 0;                        // positions of this dword with windows of their own
+        for (int i = 31; i >= 0; --i) {
+            if (!((w >> i) & 1u)) nz = 32 * j + i;
+            const int r = min(nz - (32 * j + i), T3_RUN_CAP);
+            run[(size_t)(32 * j + i) * 32 + q] = (uint8_t)r;
+            if (32 * j + i < n_t && r < max_m) own |= 1u << i;
+        }
+        if (own && a.debug != 3) {
+            const uint32_t k = (uint32_t)__builtin_popcount(own);
+            uint32_t at = atomicAdd(&misc[0], k);
+            for (int i = 0; i < 32; ++i)
+                if ((own >> i) & 1u) {
+                    if (at < (uint32_t)T3_WL_CAP) wl[at] = (uint32_t)q | ((uint32_t)(32 * j + i) << 8);
+                    else inline_from = min(inline_from, i);
+                    ++at;
+                }
         }
     }
     __syncthreads();
-    if (misc[1] == 0u) {                         // everything fits one pass (the usual case)
-        const uint32_t n = t3_emit(tab, misc, 0x7FFFFFFFu, out, tid);
-        if (tid == 0) {
-            hdr[0] = 1;
-            hdr[1] = (uint32_t)T << 8;
-            hdr[2] = 0;
-            hdr[3] = n;
+    if (a.debug == 2) return;
+    // (C) work items: the first path's positions, then the work list (and what did not fit it)
+    const int n_wl = (int)min(misc[0], (uint32_t)T3_WL_CAP);
+    for (int w = tid; w < n_b + n_wl + 1024; w += 1024) {
+        const uint16_t *Fp;
+        int f, n, min_m;
+        uint32_t own;
+        if (w < n_b) {
+            Fp = Fb, f = w, n = n_b, min_m = 1, own = 0u;
+        } else if (w < n_b + n_wl) {
+            const uint32_t e = wl[w - n_b];
+            const int t = (int)(e & 0xFFu);
+            f = (int)(e >> 8);
+            Fp = img0 + (size_t)t * img_stride + a.L.step_at();
+            n = (int)nlen[t];
+            min_m = (int)run[(size_t)f * 32 + t] + 1;
+            own = 1u << t;
+        } else {
+            break;
         }
-        return;
+        t3_windows_at(a, Fp, f, n, min_m, own, run, segm, cnt, lists);
     }
-    // unrelated paths: path by path, a pass is closed when the next path does not fit
-    // beside it (one path alone always does: <= 2000 windows <= cap)
-    __syncthreads();
-    t3_clear(tab, misc, tid);
-    __syncthreads();
-    int pass_start = 0, n_passes = 0;
-    uint32_t out_pos = 0;
-    for (int t = 0; t <= T; ++t) {
-        bool close = t == T;
-        if (t < T) {
-            const int n_t = (int)nlen[t];
-            const uint16_t *Fp = img0 + (size_t)t * img_stride + a.L.step_at();
-            if (tid + M <= n_t) t3_window(a, tab, misc, Fp, tid, M, 1u << t);
-            __syncthreads();
-            close = misc[0] > a.cap && t > pass_start;
+    if (inline_from < 32 && q >= 1 && q < T) {   // (unrelated paths: more positions than the list holds)
+        const int n_t = (int)nlen[q];
+        const uint16_t *Fp = img0 + (size_t)q * img_stride + a.L.step_at();
+        for (int i = inline_from; i < 32; ++i) {
+            const int f = 32 * j + i;
+            if (f >= n_t) break;
+            const int r = run[(size_t)f * 32 + q];
+            if (r >= max_m) continue;
+            t3_windows_at(a, Fp, f, n_t, r + 1, 1u << q, run, segm, cnt, lists);
         }
-        if (!close) continue;
-        const uint32_t range = ((1u << t) - 1u) & ~((1u << pass_start) - 1u);
-        const uint32_t n = t3_emit(tab, misc, range, out + out_pos, tid);
-        if (tid == 0) {
-            hdr[1 + 3 * n_passes] = (uint32_t)pass_start | ((uint32_t)t << 8);
-            hdr[2 + 3 * n_passes] = out_pos;
-            hdr[3 + 3 * n_passes] = n;
-        }
-        ++n_passes;
-        out_pos += n;
-        if (t == T) break;
-        __syncthreads();
-        t3_clear(tab, misc, tid);
-        __syncthreads();
-        pass_start = t;
-        --t;                                     // path t again, alone in a fresh table
     }
-    if (tid == 0) hdr[0] = (uint32_t)n_passes;
+    __syncthreads();
+    for (int s = tid; s < a.n_segs; s += 1024) a.list_count[(size_t)tile_rel * a.n_segs + s] = cnt[s];
 }
 
 // What only the rare paths of k_scan3 read (the overhang triage, the worklist): kept in
@@ -4074,8 +4282,8 @@ struct Scan3Args {
     const Scan3Cold *cold;
     const uint32_t *tile_masks;  // [tiles of the slab][v2p] node masks; word v2p - 2 stays zero
     const uint32_t *tile_hdr;    // [tiles of the slab][T3_THDR_WORDS]
-    const uint32_t *hdr;
-    const uint2 *list;
+    const uint32_t *list_count;  // [tiles of the slab][n_segs_total] entries of every window list
+    const uint2 *list;           // [tiles of the slab][n_segs_total][stride] {content index, tile paths}
     uint32_t stride;
     int n_paths, tile, n_tiles, tile0, debug;
     int v2p;                     // mask words per tile
@@ -4421,32 +4629,51 @@ __global__ __launch_bounds__(SCAN2_THREADS, SCAN2_WAVES_PER_SIMD) void k_scan3(S
     }
     int hdr_n = 0;
     if (lane < tv.tile_paths) hdr_n = (int)a.tile_hdr[(size_t)tile_rel * T3_THDR_WORDS + lane];
-    const uint32_t *hdr = a.hdr + ((size_t)tile_rel * a.n_segs_total + a.seg0 + seg) * T3_HDR_WORDS;
+    const uint32_t count = a.list_count[(size_t)tile_rel * a.n_segs_total + a.seg0 + seg];
     const uint2 *list = a.list + ((size_t)tile_rel * a.n_segs_total + a.seg0 + seg) * a.stride;
-    const int n_passes = (int)hdr[0];
+    const uint32_t cap = a.h_slots / 2;
 
     uint32_t cnt_good = 0, cnt_bad = 0;      // lane p: totals of tile path p over all passes
-    for (int ps = 0; ps < n_passes; ++ps) {
-        const uint32_t tt = hdr[1 + 3 * ps], begin = hdr[2 + 3 * ps], count = hdr[3 + 3 * ps];
-        const int t0 = (int)(tt & 0xFFu), t1 = (int)(tt >> 8);
+    // Passes over the tile's paths: usually one.  The window list of unrelated paths may
+    // hold more distinct contents than the table takes at load 1/2: then the range of
+    // paths is halved until it fits (one path alone always does: < 2000 windows).
+    int t0 = 0, t1 = tv.tile_paths;
+    while (t0 < tv.tile_paths) {
+        const uint32_t range = ((1u << t1) - 1u) & ~((1u << t0) - 1u);
         __syncthreads();                     // (the previous pass's probes are done)
         {
             uint4 *t4 = reinterpret_cast<uint4 *>(tab);
             for (uint32_t i = tid; i < a.h_slots / 2; i += SCAN2_THREADS)
                 t4[i] = make_uint4(KEY_EMPTY, 0u, KEY_EMPTY, 0u);
+            if (tid < 2) misc[tid] = 0;      // [0] entries [1] overflow
         }
         __syncthreads();
         for (uint32_t i = tid; i < count; i += SCAN2_THREADS) {
-            const uint2 en = list[begin + i];
+            if (*(volatile uint32_t *)&misc[1]) break;
+            const uint2 en = list[i];
+            const uint32_t m = en.y & range;
+            if (m == 0u) continue;
             uint32_t slot = en.x & tv.h_mask;
-            while (atomicCAS(&tab[2u * slot], KEY_EMPTY, en.x) != KEY_EMPTY) slot = (slot + 1u) & tv.h_mask;
-            tab[2u * slot + 1u] = en.y;
+            while (true) {                   // (identical contents of several windows: one entry)
+                const uint32_t old = atomicCAS(&tab[2u * slot], KEY_EMPTY, en.x);
+                if (old == KEY_EMPTY) {
+                    if (atomicAdd(&misc[0], 1u) + 1u > cap) misc[1] = 1u;
+                    break;
+                }
+                if (old == en.x) break;
+                slot = (slot + 1u) & tv.h_mask;
+            }
+            atomicOr(&tab[2u * slot + 1u], m);
         }
-        tv.sub_mask = ((1u << t1) - 1u) & ~((1u << t0) - 1u);
-        tv.half = (uint32_t)__builtin_popcount(tv.sub_mask) / 2u;
-        tv.gt_mask = (uint32_t)WAVE_MASK(lane >= t0 && lane < t1 && hdr_n < M);
         if constexpr (!NMG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the node masks have landed
         __syncthreads();
+        if (misc[1] != 0u && t1 - t0 > 1) {
+            t1 = t0 + (t1 - t0) / 2;
+            continue;
+        }
+        tv.sub_mask = range;
+        tv.half = (uint32_t)__builtin_popcount(tv.sub_mask) / 2u;
+        tv.gt_mask = (uint32_t)WAVE_MASK(lane >= t0 && lane < t1 && hdr_n < M);
         Seg3 sgl = sg;
         if (a.debug == 1) sgl.item_hi = sgl.item_lo;      // timing probe: no items
         Acc3<W> acc;
@@ -4464,6 +4691,8 @@ __global__ __launch_bounds__(SCAN2_THREADS, SCAN2_WAVES_PER_SIMD) void k_scan3(S
         acc.finish(tv, lane);
         cnt_good += acc.good;
         cnt_bad += acc.bad;
+        t0 = t1;
+        t1 = tv.tile_paths;
     }
     // workgroup reduction through LDS (the table is dead now), then one atomic per
     // counter per workgroup
@@ -4516,8 +4745,9 @@ struct gfal_scorer {
     bool np_scaled = true;               // record offsets are byte offsets into the node masks (else node indices)
     uint4 *d_ct_rec = nullptr;           // ContentTable::rec
     // k_tile / k_scan3 per-call buffers: node masks and header per tile, window lists per
-    // (tile, length), the cold arguments
-    uint32_t *d_tile_masks = nullptr, *d_t3_hdr = nullptr, *d_tile_hdr = nullptr;
+    // (tile, length) and their lengths (d_t3_hdr), the cold arguments
+    uint32_t *d_tile_masks = nullptr, *d_t3_hdr = nullptr, *d_tile_hdr = nullptr, *d_t3_ref = nullptr;
+    size_t t3_ref_cap = 0;
     uint2 *d_t3_list = nullptr;
     size_t tile_masks_cap = 0, t3_hdr_cap = 0, t3_list_cap = 0, tile_hdr_cap = 0;
     Scan3Cold *d_cold = nullptr, *h_cold = nullptr;      // h_cold: pinned ring of COLD_RING structs
@@ -4656,7 +4886,7 @@ void free_scorer(gfal_scorer *s)
     void *bufs[] = {s->d_item_pairs, s->d_item_pbase, s->d_item_common, s->d_item_hdr, s->d_item_weight,
                     s->d_item_hash, s->d_item_pairs0, s->d_lids, s->d_segs,
                     s->d_rec3, s->d_item_r3, s->d_segs3, s->d_ct_rec, s->d_tile_masks, s->d_t3_hdr, s->d_t3_list,
-                    s->d_tile_hdr, s->d_cold,
+                    s->d_tile_hdr, s->d_cold, s->d_t3_ref,
                     s->d_len_bins, s->d_order,
                     s->d_counts_slot,
                     s->d_node_local, s->d_node_hist, s->d_item_steps, s->d_item_base,
@@ -5283,13 +5513,13 @@ static int create_impl(const int32_t *aln_off, const int32_t *aln_steps, int64_t
                     const uint16_t *px = ls + aln_off[is.idx[l]];
                     const uint32_t w = is.wt ? is.wt[l] : 1u;
                     if (is.wt) item_weight[it * WAVE + (size_t)l] = w;
-                    uint32_t wh = whash_init(m);
+                    uint32_t wh = whash_init();
                     for (int t = 0; t < m; ++t) {
                         steps[(size_t)t * WAVE + l] = px[t];
                         h[px[t] >> 1] += w;
                         wh = whash_step(wh, px[t]);
                     }
-                    item_hash[it * WAVE + (size_t)l] = whash_final(wh);
+                    item_hash[it * WAVE + (size_t)l] = whash_final(wh, m);
                     for (int k = 0; k < K; ++k)
                         pairs[(size_t)k * WAVE + l] =
                             (uint32_t)px[2 * k + 1] |
@@ -5643,16 +5873,18 @@ static int launch_scan3(gfal_scorer *s, hipStream_t st, const Items &items, cons
     const size_t per_tile = (size_t)n_segs * stride * sizeof(uint2);
     const int slab_tiles = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_tiles, list_limit / std::max<size_t>(per_tile, 1)));
     {
-        const size_t want_masks = (size_t)slab_tiles * v2p, want_hdr = (size_t)slab_tiles * n_segs * T3_HDR_WORDS,
+        const size_t want_masks = (size_t)slab_tiles * v2p, want_hdr = (size_t)slab_tiles * n_segs,
                      want_list = (size_t)slab_tiles * n_segs * stride, want_thdr = (size_t)slab_tiles * T3_THDR_WORDS;
+        const size_t want_ref = (size_t)n_segs * 2 * L.nm;
         if (want_masks > s->tile_masks_cap || want_hdr > s->t3_hdr_cap || want_list > s->t3_list_cap ||
-            want_thdr > s->tile_hdr_cap || !s->d_cold) {
+            want_thdr > s->tile_hdr_cap || want_ref > s->t3_ref_cap || !s->d_cold) {
             if (s->have_last) HIP_TRY(hipStreamSynchronize(s->last_stream));
             int rc;
             if ((rc = dev_reserve(&s->d_tile_masks, &s->tile_masks_cap, want_masks))) return rc;
             if ((rc = dev_reserve(&s->d_t3_hdr, &s->t3_hdr_cap, want_hdr))) return rc;
             if ((rc = dev_reserve(&s->d_t3_list, &s->t3_list_cap, want_list))) return rc;
             if ((rc = dev_reserve(&s->d_tile_hdr, &s->tile_hdr_cap, want_thdr))) return rc;
+            if ((rc = dev_reserve(&s->d_t3_ref, &s->t3_ref_cap, want_ref))) return rc;
             if (!s->d_cold) {
                 HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_cold), sizeof(Scan3Cold)));
                 HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s->h_cold), COLD_RING * sizeof(Scan3Cold),
@@ -5683,12 +5915,13 @@ static int launch_scan3(gfal_scorer *s, hipStream_t st, const Items &items, cons
     ta.tile = tile;
     ta.segs = s->d_segs;
     ta.n_segs = n_segs;
-    ta.cap = h_slots / 2;
     ta.filter = filter ? 1 : 0;
+    ta.debug = getenv("GFAL_DEBUG_TILE") ? atoi(getenv("GFAL_DEBUG_TILE")) : 0;
     ta.v2p = v2p;
     ta.tile_hdr = s->d_tile_hdr;
     ta.tile_masks = s->d_tile_masks;
-    ta.hdr = s->d_t3_hdr;
+    ta.list_count = s->d_t3_hdr;
+    ta.ref = s->d_t3_ref;
     ta.list = s->d_t3_list;
     ta.stride = stride;
 
@@ -5698,7 +5931,7 @@ static int launch_scan3(gfal_scorer *s, hipStream_t st, const Items &items, cons
     a3.cold = s->d_cold;
     a3.tile_masks = s->d_tile_masks;
     a3.tile_hdr = s->d_tile_hdr;
-    a3.hdr = s->d_t3_hdr;
+    a3.list_count = s->d_t3_hdr;
     a3.list = s->d_t3_list;
     a3.stride = stride;
     a3.n_paths = n_paths;
@@ -5728,10 +5961,13 @@ static int launch_scan3(gfal_scorer *s, hipStream_t st, const Items &items, cons
     for (int t0 = 0; t0 < n_tiles; t0 += slab_tiles) {
         const int nt = std::min(slab_tiles, n_tiles - t0);
         ta.tile0 = t0;
-        hipLaunchKernelGGL(k_tile_masks, dim3((unsigned)nt), dim3(1024), mask_bytes, st, ta,
+        ta.n_launch_tiles = nt;
+        // (the reference blocks ride along with the first slab's masks)
+        const unsigned ref_blocks = t0 == 0 ? (unsigned)(((size_t)n_segs * L.nm + 1023) / 1024) : 0u;
+        hipLaunchKernelGGL(k_tile_masks, dim3((unsigned)nt + ref_blocks), dim3(1024), mask_bytes, st, ta,
                            (const Scan3Cold *)cold, t0 == 0 ? s->d_cold : (Scan3Cold *)nullptr,
                            (int)sizeof(Scan3Cold));
-        hipLaunchKernelGGL(k_tile, dim3((unsigned)nt, (unsigned)n_segs), dim3(1024), (size_t)T3_TILE_LDS, st, ta);
+        hipLaunchKernelGGL(k_tile, dim3((unsigned)nt), dim3(1024), t3_tile_lds(n_segs), st, ta);
         HIP_TRY(hipGetLastError());
         a3.tile0 = t0;
         a3.n_tiles = nt;
