@@ -3688,7 +3688,8 @@ __global__ __launch_bounds__(256) void k_store_paths(const int32_t *__restrict__
 // --------------------------------------------------------------------------
 constexpr int T3_MAX = 31;                 // tile paths: bits 0..30 of a node mask (bit 31: NOT_A0)
 constexpr uint32_t KEY_EMPTY = 0xFFFFFFFFu;
-constexpr int T3_THDR_WORDS = 128;         // per tile: 32 lengths | 32 first steps | 32 common prefixes with path 0
+constexpr int T3_THDR_WORDS = 384;         // per tile: 32 lengths | 32 first steps | 32 common prefixes with path 0 | 32 x the first 16 steps (8 dwords)
+constexpr int T3_THDR_PRE = 96;
 constexpr int T3_CT_INLINE = 5;            // steps of an alignment a content-table record carries
 
 struct ContentTable {
@@ -3778,6 +3779,8 @@ __global__ __launch_bounds__(1024) void k_tile_masks(TileArgs a, const Scan3Cold
         if (lo) lcp = min(lcp, 2 * __builtin_ctzll(lo));
         if (hi) lcp = min(lcp, 2 * __builtin_ctzll(hi) + 1);
         if (l == 0) a.tile_hdr[(size_t)blockIdx.x * T3_THDR_WORDS + 64 + t] = (uint32_t)lcp;
+        // the path's first 16 steps, for k_scan3's overhang test
+        if (l < 8) a.tile_hdr[(size_t)blockIdx.x * T3_THDR_WORDS + T3_THDR_PRE + t * 8 + l] = l < nm / 2 ? pt[l] : 0xFFFFFFFFu;
     }
     for (int t = 0; t < T; ++t) {
         const uint32_t *lsrc = reinterpret_cast<const uint32_t *>(a.lids + (size_t)(path0 + t) * nm);
@@ -4278,6 +4281,7 @@ struct Seg3 {
 
 struct Scan3Args {
     const uint32_t *rec3;        // item records
+    const uint16_t *item_steps;  // Items::steps (the overhang test reads an alignment's steps)
     const uint32_t *common;      // Items::common
     const Scan3Cold *cold;
     const uint32_t *tile_masks;  // [tiles of the slab][v2p] node masks; word v2p - 2 stays zero
@@ -4293,6 +4297,7 @@ struct Scan3Args {
     unsigned long long chunk_mult, chunk_inv_min;
     uint32_t h_slots;            // table slots of a workgroup (power of two)
     uint32_t *counts;
+    uint32_t *counts_dbg;        // the scorer's status words (diagnostic builds count into words 4..7)
 };
 
 typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
@@ -4304,7 +4309,13 @@ __device__ __forceinline__ uint2 lds_entry(uint32_t byte_addr)
     return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
 }
 
+// a workgroup's pairs for the exact DP (LDS words): cursor, end of the valid entries, per-path
+// histogram, then WL3_CAP entries of 8 bytes
+constexpr int WL3_CUR = 0, WL3_END = 1, WL3_HIST = 2, WL3_BUF = 34, WL3_CAP = 512;
+constexpr int WL3_WORDS = WL3_BUF + 2 * WL3_CAP;
+
 struct Tile3 {
+    uint32_t *wl_lds;            // [WL3_WORDS]
     const char *gmask;           // NMG: the tile's node masks in HBM
     int nm_shift;
     uint32_t tab_base;           // LDS byte address of the table
@@ -4387,6 +4398,18 @@ struct Acc3 {
             }
         }
     }
+    // pairs counted as bad that the overhang test hands to the exact DP after all
+    __device__ __forceinline__ void uncount_bad(uint32_t cand, uint32_t w, int lane)
+    {
+        for (uint32_t u = wave_or_dpp(cand); u; u &= u - 1u) {
+            const int p = __builtin_ctz(u);
+            const bool c = ((cand >> p) & 1u) != 0u;
+            uint32_t d;
+            if constexpr (W) d = wave_add_dpp(c ? w : 0u);
+            else d = (uint32_t)__popcll(WAVE_MASK(c));
+            if (lane == p) bad -= d;
+        }
+    }
     __device__ __forceinline__ void finish(const Tile3 &tv, int lane)
     {
         uint32_t sg = fg, sb = fb;
@@ -4406,25 +4429,33 @@ template <int P0, bool W>
 struct Item3Regs {
     uint32_t key, w;
     uint32_t np[P0 > 0 ? P0 : 1];
-    uint32_t it;                 // (uniform) the item
+    int src;                     // (uniform) the item's rank in its group of 64
 };
 
 // The rare part of an item: lanes whose alignment is not a subpath of some tile path but
 // touches the tile's first node.  The traceback stays free only if a proper suffix of B
 // (or of rc(B)) equals a prefix of the path; survivors of this exact test go to the DP
-// kernels (as in k_scan2; everything is read from HBM here).
+// kernels.  The alignment's steps are loaded in one go (P0 > 0: at most 2 P0 of them) and
+// compared in registers with the path's first steps from the tile header (uniform:
+// scalar loads); tile paths that share their first M - 1 steps with the tile's first
+// path (nearly always all of them) are decided together.
+template <int P0>
 __device__ __forceinline__ uint32_t scan3_triage(const Scan3Args &a, const Tile3 &tv, const Seg3 &sg,
                                                  uint32_t it, uint32_t open, bool has_a0, int tile_rel, int lane)
 {
-    const Scan3Cold c = *a.cold;
     const int M = (int)sg.m;
+    const uint32_t *thdr = a.tile_hdr + (size_t)tile_rel * T3_THDR_WORDS;
     uint32_t cfw = 0, crc = 0;
-    const uint16_t *bp = c.item_steps + ((size_t)sg.step_base + (size_t)(it - sg.item_lo) * (uint32_t)M) * WAVE + lane;
+    const uint16_t *bp = a.item_steps + ((size_t)sg.step_base + (size_t)(it - sg.item_lo) * (uint32_t)M) * WAVE + lane;
+    constexpr int NB = P0 > 0 ? 2 * P0 : 1;
+    uint32_t b[NB];
+    if constexpr (P0 > 0) {
+#pragma unroll
+        for (int t = 0; t < NB; ++t) b[t] = t < M ? (uint32_t)bp[t * WAVE] : 0xFFFFu;
+    }
     uint32_t want = wave_or_dpp(has_a0 ? open : 0u);
-    // the test reads the first M - 1 steps of a path: tile paths that share them with the
-    // tile's first path (nearly always all of them) are decided together
     uint32_t my_lcp = 0;
-    if (lane < tv.tile_paths) my_lcp = a.tile_hdr[(size_t)tile_rel * T3_THDR_WORDS + 64 + lane];
+    if (lane < tv.tile_paths) my_lcp = thdr[64 + lane];
     const uint32_t class0 = (uint32_t)WAVE_MASK(lane < tv.tile_paths && (int)my_lcp >= M - 1);
     while (want) {
         const int p = __builtin_ctz(want);
@@ -4432,37 +4463,91 @@ __device__ __forceinline__ uint32_t scan3_triage(const Scan3Args &a, const Tile3
         want &= ~grp;
         const uint32_t mine_bits = has_a0 ? (open & grp) : 0u;
         const bool mine = mine_bits != 0u;
-        const uint32_t a0 = a.tile_hdr[(size_t)tile_rel * T3_THDR_WORDS + 32 + p];
-        const uint32_t *pstep32 = reinterpret_cast<const uint32_t *>(
-            c.images + (size_t)(tv.path0 + p) * c.L.total + c.L.step_at());
         bool cand_fw = false, cand_rc = false;
-        for (int t = 0; t < M; ++t) {
-            const uint32_t bt = bp[t * WAVE];
-            const bool live_fw = mine && t >= 1 && bt == a0;
-            if (WAVE_ANY(live_fw)) cand_fw |= tail_equals(bp, t, 1, M - t, 0u, pstep32, live_fw);
-            const bool live_rc = mine && t < M - 1 && (bt ^ 1u) == a0;
-            if (WAVE_ANY(live_rc)) cand_rc |= tail_equals(bp, t, -1, t + 1, 1u, pstep32, live_rc);
+        if constexpr (P0 > 0) {
+            const uint32_t *pre = thdr + T3_THDR_PRE + p * 8;        // (uniform)
+            auto stepA = [&](int k) -> uint32_t { return (pre[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu; };
+            const uint32_t a0 = stepA(0);
+#pragma unroll
+            for (int t = 0; t < NB; ++t) {
+                if (t >= 1 && t < M) {                     // B[t..M) == path[0..M-t) ?
+                    bool eq = mine && b[t] == a0;
+#pragma unroll
+                    for (int k = 1; k < NB - t; ++k)
+                        if (t + k < M) eq &= b[t + k] == stepA(k);
+                    cand_fw |= eq;
+                }
+                if (t < M - 1) {                           // rc(B)[M-1-t..M) == path[0..t+1) ?
+                    bool eq = mine && (b[t] ^ 1u) == a0;
+#pragma unroll
+                    for (int k = 1; k <= t; ++k) eq &= (b[t - k] ^ 1u) == stepA(k);
+                    cand_rc |= eq;
+                }
+            }
+        } else {
+            const Scan3Cold c = *a.cold;
+            const uint32_t a0 = thdr[32 + p];
+            const uint32_t *pstep32 = reinterpret_cast<const uint32_t *>(
+                c.images + (size_t)(tv.path0 + p) * c.L.total + c.L.step_at());
+            for (int t = 0; t < M; ++t) {
+                const uint32_t bt = bp[t * WAVE];
+                const bool live_fw = mine && t >= 1 && bt == a0;
+                if (WAVE_ANY(live_fw)) cand_fw |= tail_equals(bp, t, 1, M - t, 0u, pstep32, live_fw);
+                const bool live_rc = mine && t < M - 1 && (bt ^ 1u) == a0;
+                if (WAVE_ANY(live_rc)) cand_rc |= tail_equals(bp, t, -1, t + 1, 1u, pstep32, live_rc);
+            }
         }
         cfw |= cand_fw ? mine_bits : 0u;
         crc |= cand_rc ? mine_bits : 0u;
     }
-    push_item_pairs(c.worklist, c.wl_count, c.wl_capacity, c.wl_hist, c.status, c.n_paths, cfw, crc, lane,
-                    (uint32_t)tv.path0, tv.tile_paths, it * WAVE + (uint32_t)lane, M);
-    return cfw | crc;
+    // The pairs for the exact DP are gathered per workgroup (LDS) and leave it with ONE
+    // atomic on the list's cursor: every returning atomic on that one word costs a round
+    // trip to L2 and they serialise chip-wide (67 k items take the test per config-3 step:
+    // 0.29 of 0.63 ms went there).  What does not fit the buffer goes the direct way.
+    const uint32_t any = cfw | crc;
+    const uint32_t uany = wave_or_dpp(any);          // (uniform) the tile paths with a pair
+    if (uany) {
+        uint32_t total = 0;
+        for (uint32_t u = uany; u; u &= u - 1u)
+            total += (uint32_t)__popcll(WAVE_MASK(((any >> __builtin_ctz(u)) & 1u) != 0u));
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&tv.wl_lds[WL3_CUR], total);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (base + total <= (uint32_t)WL3_CAP) {
+            unsigned long long *buf = reinterpret_cast<unsigned long long *>(tv.wl_lds + WL3_BUF);
+            for (uint32_t u = uany; u; u &= u - 1u) {
+                const int p = __builtin_ctz(u);
+                const bool mine = ((any >> p) & 1u) != 0u;
+                const lanemask m = WAVE_MASK(mine);
+                if (lane == 0) atomicAdd(&tv.wl_lds[WL3_HIST + p], (uint32_t)__popcll(m));
+                if (mine)
+                    buf[base + lanes_below(m, lane)] =
+                        (((cfw >> p) & 1u) ? WL_FW : 0ull) | (((crc >> p) & 1u) ? WL_RC : 0ull) |
+                        ((unsigned long long)(tv.path0 + p) << 32) | (it * WAVE + (uint32_t)lane);
+                base += (uint32_t)__popcll(m);
+            }
+        } else {
+            if (lane == 0) atomicMin(&tv.wl_lds[WL3_END], base);
+            const Scan3Cold c = *a.cold;
+            push_item_pairs(c.worklist, c.wl_count, c.wl_capacity, c.wl_hist, c.status, c.n_paths, cfw, crc, lane,
+                            (uint32_t)tv.path0, tv.tile_paths, it * WAVE + (uint32_t)lane, M);
+        }
+    }
+    return any;
 }
 
 // One item against the tile, from the lane's registers: key, pm = AND of the node masks of
 // the lane's alignment (bits 0..30: every node is on tile path p -- the filter of
 // src/eval.cpp:81-91; bit 31: none is the tile's first node), e = the table entry of the
-// key's home slot.
-template <bool W>
-__device__ __forceinline__ void scan3_decide(const Scan3Args &a, const Tile3 &tv, const Seg3 &sg,
-                                             uint32_t key, uint32_t w, uint32_t it, uint32_t pm, uint2 e,
-                                             int tile_rel, int lane, Acc3<W> &acc)
+// key's home slot.  Returns the tile paths the alignment passes the filter for but is no
+// subpath of (`open`), good_mask = the paths it is good for without further tests.
+__device__ __forceinline__ uint32_t scan3_resolve(const Tile3 &tv, uint32_t key, uint32_t pm, uint2 e,
+                                                  uint32_t &good_mask)
 {
     const uint32_t pass = pm & tv.sub_mask;
     const uint32_t todo = pass & ~tv.gt_mask;       // (src/alignments.cpp:500: m > n -> good)
     // ---- which of the tile's paths contain exactly this step sequence ----
+#if !defined(GFAL_ABLATE3) || (GFAL_ABLATE3 != 5 && GFAL_ABLATE3 != 6)      // (timing probe: home slot only)
     if (__builtin_expect(WAVE_ANY(todo != 0u && e.x != key && e.x != KEY_EMPTY), 0)) {      // (the home slot is taken)
         uint32_t slot = key & tv.h_mask;
         bool more = todo != 0u && e.x != key && e.x != KEY_EMPTY;
@@ -4474,20 +4559,44 @@ __device__ __forceinline__ void scan3_decide(const Scan3Args &a, const Tile3 &tv
             more = more && e.x != key && e.x != KEY_EMPTY;
         }
     }
+#endif
     const uint32_t have = (e.x == key ? e.y : 0u) | tv.gt_mask;
-    const uint32_t good_mask = pass & have;
-    const uint32_t open = pass & ~have;
-    uint32_t bad_mask = open;
-    const bool has_a0 = (int32_t)pm >= 0;
-    if (__builtin_expect(WAVE_ANY(open != 0u && has_a0), 0))
-        bad_mask &= ~scan3_triage(a, tv, sg, it, open, has_a0, tile_rel, lane);
-    acc.add(good_mask, bad_mask, tv, w, lane);
+    good_mask = pass & have;
+    return pass & ~have;
+}
+
+// The hot path of an item.  Lanes whose alignment is open for some path AND touches the
+// tile's first node need the overhang test: the item is only MARKED here (bit `src` of
+// `tri`) and its open pairs are counted as bad for now; scan3_fixup settles them after
+// the group's items -- the test's registers stay out of this loop (with the test inline
+// the loop spilled 28 VGPRs and ~150 SGPRs and took twice as long).
+template <bool W>
+__device__ __forceinline__ void scan3_decide(const Tile3 &tv, uint32_t key, uint32_t w, uint32_t pm, uint2 e,
+                                             int src, lanemask &tri, int lane, Acc3<W> &acc)
+{
+    uint32_t good_mask;
+    const uint32_t open = scan3_resolve(tv, key, pm, e, good_mask);
+#if !defined(GFAL_ABLATE3) || (GFAL_ABLATE3 != 4 && GFAL_ABLATE3 != 6)      // (timing probe: no overhang test)
+    if (WAVE_ANY(open != 0u && (int32_t)pm >= 0)) tri |= 1ull << src;
+#endif
+#if defined(GFAL_ABLATE3) && GFAL_ABLATE3 == 3      // timing probe: no counting
+    acc.good += good_mask ^ open;
+    return;
+#endif
+    acc.add(good_mask, open, tv, w, lane);
 }
 
 template <int P0, bool W, bool NMG>
-__device__ __forceinline__ void scan3_item(const Scan3Args &a, const Tile3 &tv, const Seg3 &sg,
-                                           const Item3Regs<P0, W> &r, int tile_rel, int lane, Acc3<W> &acc)
+__device__ __forceinline__ void scan3_item(const Tile3 &tv, const Item3Regs<P0, W> &r, lanemask &tri, int lane,
+                                           Acc3<W> &acc)
 {
+#if defined(GFAL_ABLATE3) && GFAL_ABLATE3 == 1      // timing probe: the loads only
+    uint32_t x = r.key;
+#pragma unroll
+    for (int k = 0; k < P0; ++k) x ^= r.np[k];
+    acc.good += x;
+    return;
+#endif
     // the probe goes out together with the node-mask reads: one LDS round trip
     const uint2 e = lds_entry(tv.tab_base + ((r.key & tv.h_mask) << 3));
     uint32_t pm = 0xFFFFFFFFu;
@@ -4496,7 +4605,34 @@ __device__ __forceinline__ void scan3_item(const Scan3Args &a, const Tile3 &tv, 
         pm &= nm_read<NMG>(tv, r.np[k] & 0xFFFFu);
         pm &= nm_read<NMG>(tv, r.np[k] >> 16);
     }
-    scan3_decide<W>(a, tv, sg, r.key, r.w, r.it, pm, e, tile_rel, lane, acc);
+#if defined(GFAL_ABLATE3) && GFAL_ABLATE3 == 2      // timing probe: loads + LDS reads
+    acc.good += pm ^ e.x ^ e.y;
+    return;
+#endif
+    scan3_decide<W>(tv, r.key, r.w, pm, e, r.src, tri, lane, acc);
+}
+
+// A marked item again, now with the overhang test: the pairs it hands to the exact DP
+// were counted as bad by the hot path.
+template <int P0, bool W, bool NMG>
+__device__ __forceinline__ void scan3_fixup(const Scan3Args &a, const Tile3 &tv, const Seg3 &sg, uint32_t it,
+                                            int tile_rel, int lane, Acc3<W> &acc)
+{
+    const int P0rt = ((int)sg.m + 1) / 2;
+    const uint32_t *pp = a.rec3 + ((size_t)sg.r3_base + (size_t)(it - sg.item_lo) * (1 + P0rt + (W ? 1 : 0))) * WAVE + lane;
+    const uint32_t key = pp[0];
+    const uint32_t w = W ? pp[(size_t)(P0rt + 1) * WAVE] : 1u;
+    const uint2 e = lds_entry(tv.tab_base + ((key & tv.h_mask) << 3));
+    uint32_t pm = 0xFFFFFFFFu;
+    for (int k = 0; k < P0rt; ++k) {
+        const uint32_t x = pp[(size_t)(k + 1) * WAVE];
+        pm &= nm_read<NMG>(tv, x & 0xFFFFu);
+        pm &= nm_read<NMG>(tv, x >> 16);
+    }
+    uint32_t good_mask;
+    const uint32_t open = scan3_resolve(tv, key, pm, e, good_mask);
+    const uint32_t cand = scan3_triage<P0>(a, tv, sg, it, open, (int32_t)pm >= 0, tile_rel, lane);
+    acc.uncount_bad(cand, w, lane);
 }
 
 // The wave's items of one segment chunk, 64 at a time: one ballot drops the items none
@@ -4525,11 +4661,12 @@ __device__ __forceinline__ void scan3_items(const Scan3Args &a, const Tile3 &tv,
         }
         lanemask todo = WAVE_MASK(keep);
         if (todo == 0) continue;
+        lanemask tri = 0;                // items of this group that need the overhang test
         if constexpr (P0 > 0) {
             auto load_item = [&](int src_in, Item3Regs<P0, W> &r) {
                 const int src = __builtin_amdgcn_readfirstlane(src_in);
                 const uint32_t it = (uint32_t)(it0 + src * item_stride);
-                r.it = it;
+                r.src = src;
                 const GLOBAL_AS uint32_t *pp =
                     sgpr_ptr(a.rec3 + ((size_t)sg.r3_base + (size_t)(it - sg.item_lo) * (P0 + 1 + (W ? 1 : 0))) * WAVE) + ulane;
                 r.key = pp[0];
@@ -4542,12 +4679,12 @@ __device__ __forceinline__ void scan3_items(const Scan3Args &a, const Tile3 &tv,
             while (true) {
                 lanemask rest = todo & (todo - 1);
                 load_item(__builtin_ctzll(rest ? rest : todo), rb);
-                scan3_item<P0, W, NMG>(a, tv, sg, ra, tile_rel, lane, acc);
+                scan3_item<P0, W, NMG>(tv, ra, tri, lane, acc);
                 if (rest == 0) break;
                 todo = rest;
                 rest = todo & (todo - 1);
                 load_item(__builtin_ctzll(rest ? rest : todo), ra);
-                scan3_item<P0, W, NMG>(a, tv, sg, rb, tile_rel, lane, acc);
+                scan3_item<P0, W, NMG>(tv, rb, tri, lane, acc);
                 if (rest == 0) break;
                 todo = rest;
             }
@@ -4565,8 +4702,12 @@ __device__ __forceinline__ void scan3_items(const Scan3Args &a, const Tile3 &tv,
                     pm &= nm_read<NMG>(tv, x & 0xFFFFu);
                     pm &= nm_read<NMG>(tv, x >> 16);
                 }
-                scan3_decide<W>(a, tv, sg, key, w, it, pm, e, tile_rel, lane, acc);
+                scan3_decide<W>(tv, key, w, pm, e, src, tri, lane, acc);
             }
+        }
+        for (; tri != 0; tri &= tri - 1) {
+            const int src = __builtin_amdgcn_readfirstlane(__builtin_ctzll(tri));
+            scan3_fixup<P0, W, NMG>(a, tv, sg, (uint32_t)(it0 + src * item_stride), tile_rel, lane, acc);
         }
     }
 }
@@ -4614,7 +4755,9 @@ __global__ __launch_bounds__(SCAN2_THREADS, SCAN2_WAVES_PER_SIMD) void k_scan3(S
     tv.nm_shift = a.nm_shift;
     // LDS: node masks first (address = the record's byte offset: no base to add), then the table
     uint32_t *tab = lds32 + (NMG ? 0 : v2p);
-    uint32_t *misc = tab + 2 * a.h_slots;
+    uint32_t *misc = tab + 2 * a.h_slots;    // [64]
+    tv.wl_lds = misc + 2 * MAX_TILE;
+    if (tid < WL3_BUF) tv.wl_lds[tid] = tid == WL3_END ? 0xFFFFFFFFu : 0u;
     const uint32_t *gmask = a.tile_masks + (size_t)tile_rel * v2p;
     tv.gmask = reinterpret_cast<const char *>(gmask);
     tv.tab_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)tab;
@@ -4703,7 +4846,30 @@ __global__ __launch_bounds__(SCAN2_THREADS, SCAN2_WAVES_PER_SIMD) void k_scan3(S
         if (cnt_bad) atomicAdd(&misc[lane], cnt_bad);
         if (cnt_good) atomicAdd(&misc[MAX_TILE + lane], cnt_good);
     }
+    // the workgroup's pairs for the exact DP: one atomic on the list's cursor
+    const uint32_t n_wl = min(tv.wl_lds[WL3_CUR], tv.wl_lds[WL3_END]);
     __syncthreads();
+    if (n_wl) {
+        const Scan3Cold c = *a.cold;
+        if (tid == 0) {
+            const unsigned long long g = atomicAdd(c.wl_count, (unsigned long long)n_wl);
+            tv.wl_lds[WL3_CUR] = (uint32_t)g;
+            tv.wl_lds[WL3_END] = (uint32_t)(g >> 32);
+        }
+        __syncthreads();
+        const unsigned long long g = (unsigned long long)tv.wl_lds[WL3_CUR] | ((unsigned long long)tv.wl_lds[WL3_END] << 32);
+        const unsigned long long *buf = reinterpret_cast<const unsigned long long *>(tv.wl_lds + WL3_BUF);
+        bool overflow = false;
+        for (uint32_t i = tid; i < n_wl; i += SCAN2_THREADS) {
+            if (g + i < c.wl_capacity) c.worklist[g + i] = buf[i];
+            else overflow = true;
+        }
+        if (overflow) atomicOr(c.status, ST_DP_OVERFLOW);
+        if (tid < tv.tile_paths) {
+            const uint32_t h = tv.wl_lds[WL3_HIST + tid];
+            if (h) atomicAdd(&c.wl_hist[(uint32_t)length_class(M) * (uint32_t)c.n_paths + tv.path0 + tid], h);
+        }
+    }
     if (tid < tv.tile_paths) {
         const uint32_t d = misc[tid], g = misc[MAX_TILE + tid];
         if (d) atomicAdd(&a.counts[tv.path0 + tid], d);
@@ -5855,16 +6021,17 @@ static int launch_scan3(gfal_scorer *s, hipStream_t st, const Items &items, cons
     const size_t mask_bytes = (size_t)v2p * sizeof(uint32_t);
     uint32_t h_slots = 8192;
     bool nmg = !s->np_scaled;
-    if (mask_bytes + (size_t)h_slots * 8 + 256 > (size_t)LDS_BUDGET) h_slots = 4096;
-    if (mask_bytes + (size_t)h_slots * 8 + 256 > (size_t)LDS_BUDGET) nmg = true;
+    const size_t fixed3 = 256 + (size_t)WL3_WORDS * 4;      // reduction words + the workgroup's pairs for the DP
+    if (mask_bytes + (size_t)h_slots * 8 + fixed3 > (size_t)LDS_BUDGET) h_slots = 4096;
+    if (mask_bytes + (size_t)h_slots * 8 + fixed3 > (size_t)LDS_BUDGET) nmg = true;
     if (const char *env = getenv("GFAL_SCAN3_NMG")) nmg = nmg || atoi(env) != 0;
     if (nmg) h_slots = 8192;
     if (const char *env = getenv("GFAL_SCAN3_SLOTS")) {
         const int v = atoi(env);
-        if ((v == 4096 || v == 8192) && (nmg ? 0 : mask_bytes) + (size_t)v * 8 + 256 <= (size_t)LDS_BUDGET)
+        if ((v == 4096 || v == 8192) && (nmg ? 0 : mask_bytes) + (size_t)v * 8 + fixed3 <= (size_t)LDS_BUDGET)
             h_slots = (uint32_t)v;
     }
-    const size_t lds3 = (nmg ? 0 : mask_bytes) + (size_t)h_slots * 8 + 256;
+    const size_t lds3 = (nmg ? 0 : mask_bytes) + (size_t)h_slots * 8 + fixed3;
     const uint32_t stride = (uint32_t)tile * 2u * (uint32_t)max_path_len;
     // slabs of tiles: the window lists of a slab stay below GFAL_SCAN3_LIST_MB (worst case:
     // every window of every path its own entry; what is touched is what exists)
@@ -5928,6 +6095,7 @@ static int launch_scan3(gfal_scorer *s, hipStream_t st, const Items &items, cons
     Scan3Args a3;
     a3.rec3 = s->d_rec3;
     a3.common = items.common;
+    a3.item_steps = items.steps;
     a3.cold = s->d_cold;
     a3.tile_masks = s->d_tile_masks;
     a3.tile_hdr = s->d_tile_hdr;
@@ -5942,6 +6110,7 @@ static int launch_scan3(gfal_scorer *s, hipStream_t st, const Items &items, cons
     a3.n_segs_total = n_segs;
     a3.h_slots = h_slots;
     a3.counts = d_counts;
+    a3.counts_dbg = s->d_status;
     // chunks per segment: in proportion to the segment's items (see k_scan2's launch)
     int y_want = (want_groups + n_tiles - 1) / n_tiles;
     int min_items = 24 * SCAN2_WAVES;
@@ -7402,6 +7571,10 @@ int gfal_scorer_get_info(gfal_scorer *s, gfal_info *out)
 #endif
 #if defined(GFAL_ABLATE) && GFAL_ABLATE == 7
         fprintf(stderr, "(item, tile) visits %u, rejected through the common node %u\n", host[5], host[4]);
+#endif
+#if defined(GFAL_ABLATE3) && GFAL_ABLATE3 == 7
+        fprintf(stderr, "k_scan3: item visits %u, with an open pair %u, taking the overhang test %u (%u lanes)\n", host[4],
+                host[7], host[5], host[6]);
 #endif
         if (s->profiling && s->ev_calls > 0) {
             const int n = std::min(s->ev_calls, (int)gfal_scorer::EV_RING);
