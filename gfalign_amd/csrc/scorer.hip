@@ -3766,11 +3766,12 @@ __global__ __launch_bounds__(1024) void k_tile_masks(TileArgs a, const Scan3Cold
         }
     }
     __syncthreads();
-    // how many of its first 64 steps every path shares with the tile's first path
-    // (k_scan3's overhang test looks at M - 1 leading steps)
+    // how many of its first 64 steps every path shares with the batch's longest path (image
+    // slot 0): k_scan3's overhang test looks at M - 1 leading steps, and for the paths that
+    // share them with that one path the answer was worked out per alignment (k_overhang)
     for (int t = tid >> 6; t < T; t += 1024 / WAVE) {
         const int l = tid & (WAVE - 1);
-        const uint32_t *p0 = reinterpret_cast<const uint32_t *>(a.images + (size_t)path0 * a.L.total + a.L.step_at());
+        const uint32_t *p0 = reinterpret_cast<const uint32_t *>(a.images + a.L.step_at());
         const uint32_t *pt = reinterpret_cast<const uint32_t *>(a.images + (size_t)(path0 + t) * a.L.total + a.L.step_at());
         uint32_t x = 0;
         if (l < 32 && l < nm / 2) x = p0[l] ^ pt[l];
@@ -4258,6 +4259,66 @@ __global__ __launch_bounds__(1024) void k_tile(TileArgs a)
 
 // What only the rare paths of k_scan3 read (the overhang triage, the worklist): kept in
 // HBM behind one pointer, so that none of it occupies SGPRs across the item loop.
+// The overhang test (see scan3_triage) of every alignment of up to 16 steps against the
+// first steps of the batch's longest path, once per batch: a wave per item, a lane per
+// alignment; two 64-bit masks per item (a proper suffix of B / of rc(B) equals a prefix of
+// the path).  Candidate paths of a search all start at the source: nearly every tile path
+// shares these steps, and k_scan3 then only reads the masks.
+__global__ __launch_bounds__(256) void k_overhang(Items items, int n_items, const uint16_t *images, ImageLayout L,
+                                                  uint32_t *__restrict__ ovh)
+{
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int it = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (it >= n_items) return;
+    const int M = items.len[it];
+    if (M > 16) return;                      // (k_scan3 tests those pair by pair)
+    const uint16_t *bp = items.steps + (size_t)items.base[it] * WAVE + lane;
+    const uint16_t *pre = images + L.step_at();           // image slot 0
+    uint32_t b[16], a[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        b[t] = t < M ? (uint32_t)bp[t * WAVE] : 0xFFFFu;
+        a[t] = pre[t];                       // (L.nm >= 32: always there; 0xFFFF beyond the path)
+    }
+    bool cand_fw = false, cand_rc = false;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        if (t >= 1 && t < M) {               // B[t..M) == path[0..M-t) ?
+            bool eq = true;
+#pragma unroll
+            for (int k = 0; k < 16 - t; ++k)
+                if (t + k < M) eq &= b[t + k] == a[k];
+            cand_fw |= eq;
+        }
+        if (t < M - 1) {                     // rc(B)[M-1-t..M) == path[0..t+1) ?
+            bool eq = true;
+#pragma unroll
+            for (int k = 0; k <= t; ++k) eq &= (b[t - k] ^ 1u) == a[k];
+            cand_rc |= eq;
+        }
+    }
+    const lanemask fw = WAVE_MASK(cand_fw), rc = WAVE_MASK(cand_rc);
+    if (lane == 0) {
+        ovh[(size_t)it * 4] = (uint32_t)fw;
+        ovh[(size_t)it * 4 + 1] = (uint32_t)(fw >> 32);
+        ovh[(size_t)it * 4 + 2] = (uint32_t)rc;
+        ovh[(size_t)it * 4 + 3] = (uint32_t)(rc >> 32);
+    }
+}
+
+// k_scan3's chunks of a segment: seg_chunks, but never fewer than keep a wave at SCAN3_GROUPS
+// groups of 64 items (the items that need the overhang test are remembered group by
+// group and settled after the wave's last item)
+constexpr int SCAN3_GROUPS = 8;
+__host__ __device__ __forceinline__ uint32_t seg_chunks3(uint32_t n_items, unsigned long long mult,
+                                                         unsigned long long inv_min)
+{
+    const uint32_t per = (uint32_t)(SCAN3_GROUPS * WAVE * (GFAL_SCAN2_THREADS / WAVE));
+    const uint32_t lo = (n_items + per - 1u) / per;
+    const uint32_t c = seg_chunks(n_items, mult, inv_min);
+    return c < lo ? (lo > 65535u ? 65535u : lo) : c;
+}
+
 struct Scan3Cold {
     const uint16_t *item_steps;  // Items::steps
     const uint16_t *images;
@@ -4282,6 +4343,7 @@ struct Seg3 {
 struct Scan3Args {
     const uint32_t *rec3;        // item records
     const uint16_t *item_steps;  // Items::steps (the overhang test reads an alignment's steps)
+    const uint32_t *ovh;         // [n_items][4] k_overhang's masks
     const uint32_t *common;      // Items::common
     const Scan3Cold *cold;
     const uint32_t *tile_masks;  // [tiles of the slab][v2p] node masks; word v2p - 2 stays zero
@@ -4316,6 +4378,7 @@ constexpr int WL3_WORDS = WL3_BUF + 2 * WL3_CAP;
 
 struct Tile3 {
     uint32_t *wl_lds;            // [WL3_WORDS]
+    uint32_t *tri_lds;           // [waves][SCAN3_GROUPS][2] per wave and group of 64 items: those that need the overhang test
     const char *gmask;           // NMG: the tile's node masks in HBM
     int nm_shift;
     uint32_t tab_base;           // LDS byte address of the table
@@ -4457,9 +4520,17 @@ __device__ __forceinline__ uint32_t scan3_triage(const Scan3Args &a, const Tile3
     uint32_t my_lcp = 0;
     if (lane < tv.tile_paths) my_lcp = thdr[64 + lane];
     const uint32_t class0 = (uint32_t)WAVE_MASK(lane < tv.tile_paths && (int)my_lcp >= M - 1);
-    while (want) {
+    if (M <= 16 && (want & class0) != 0u) {          // k_overhang has the answer for these paths
+        const uint32_t *o = a.ovh + (size_t)it * 4;
+        const lanemask fwm = (lanemask)o[0] | ((lanemask)o[1] << 32), rcm = (lanemask)o[2] | ((lanemask)o[3] << 32);
+        const uint32_t mine_bits = has_a0 ? (open & class0) : 0u;
+        cfw |= ((fwm >> lane) & 1ull) ? mine_bits : 0u;
+        crc |= ((rcm >> lane) & 1ull) ? mine_bits : 0u;
+        want &= ~class0;
+    }
+    while (want) {                                   // (paths that start differently: one by one)
         const int p = __builtin_ctz(want);
-        const uint32_t grp = ((class0 >> p) & 1u) ? class0 : (1u << p);
+        const uint32_t grp = 1u << p;
         want &= ~grp;
         const uint32_t mine_bits = has_a0 ? (open & grp) : 0u;
         const bool mine = mine_bits != 0u;
@@ -4631,6 +4702,10 @@ __device__ __forceinline__ void scan3_fixup(const Scan3Args &a, const Tile3 &tv,
     }
     uint32_t good_mask;
     const uint32_t open = scan3_resolve(tv, key, pm, e, good_mask);
+#if defined(GFAL_ABLATE3) && GFAL_ABLATE3 == 9      // timing probe: the item is re-derived, the test is skipped
+    acc.good += open ^ good_mask;
+    return;
+#endif
     const uint32_t cand = scan3_triage<P0>(a, tv, sg, it, open, (int32_t)pm >= 0, tile_rel, lane);
     acc.uncount_bad(cand, w, lane);
 }
@@ -4647,8 +4722,9 @@ __device__ __forceinline__ void scan3_items(const Scan3Args &a, const Tile3 &tv,
     const int P0rt = ((int)sg.m + 1) / 2;
     const int R = 1 + P0rt + (W ? 1 : 0);
     const uint32_t ulane = (uint32_t)lane;
+    int grp = 0;
     for (int it0 = (int)sg.item_lo + chunk + wave * n_chunks; it0 < (int)sg.item_hi;
-         it0 += WAVE * item_stride) {
+         it0 += WAVE * item_stride, ++grp) {
         const int my_it = it0 + lane * item_stride;
         bool keep = my_it < (int)sg.item_hi;
         if (keep) {
@@ -4705,9 +4781,32 @@ __device__ __forceinline__ void scan3_items(const Scan3Args &a, const Tile3 &tv,
                 scan3_decide<W>(tv, key, w, pm, e, src, tri, lane, acc);
             }
         }
+        if (tri != 0 && lane == 0) {      // (settled by scan3_fixups when the wave's items are done)
+            tv.tri_lds[(wave * SCAN3_GROUPS + grp) * 2] = (uint32_t)tri;
+            tv.tri_lds[(wave * SCAN3_GROUPS + grp) * 2 + 1] = (uint32_t)(tri >> 32);
+        }
+    }
+}
+
+// the marked items of a wave (Tile3::tri_lds), one after the other
+template <bool W, bool NMG>
+__device__ __forceinline__ void scan3_fixups(const Scan3Args &a, const Tile3 &tv, const Seg3 &sg, int chunk,
+                                             int wave, int tile_rel, int lane, Acc3<W> &acc)
+{
+#if defined(GFAL_ABLATE3) && GFAL_ABLATE3 == 8      // timing probe: items are marked, nothing is settled
+    return;
+#endif
+    const int n_chunks = (int)sg.n_chunks;
+    const int item_stride = SCAN2_WAVES * n_chunks;
+    for (int grp = 0; grp < SCAN3_GROUPS; ++grp) {
+        lanemask tri = (lanemask)tv.tri_lds[(wave * SCAN3_GROUPS + grp) * 2] |
+                       ((lanemask)tv.tri_lds[(wave * SCAN3_GROUPS + grp) * 2 + 1] << 32);
+        tri = ((lanemask)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)tri)) |
+              ((lanemask)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(tri >> 32)) << 32);
+        const int it0 = (int)sg.item_lo + chunk + wave * n_chunks + grp * WAVE * item_stride;
         for (; tri != 0; tri &= tri - 1) {
-            const int src = __builtin_amdgcn_readfirstlane(__builtin_ctzll(tri));
-            scan3_fixup<P0, W, NMG>(a, tv, sg, (uint32_t)(it0 + src * item_stride), tile_rel, lane, acc);
+            const int src = __builtin_ctzll(tri);
+            scan3_fixup<0, W, NMG>(a, tv, sg, (uint32_t)(it0 + src * item_stride), tile_rel, lane, acc);
         }
     }
 }
@@ -4728,7 +4827,7 @@ __global__ __launch_bounds__(SCAN2_THREADS, SCAN2_WAVES_PER_SIMD) void k_scan3(S
         Seg3 mine{0u, 0u, 0u, 0u, 0u, 0u};
         if (lane < a.n_segs) mine = a.segs[lane];
         const uint32_t c = lane < a.n_segs
-                               ? seg_chunks(mine.item_hi - mine.item_lo, a.chunk_mult, a.chunk_inv_min)
+                               ? seg_chunks3(mine.item_hi - mine.item_lo, a.chunk_mult, a.chunk_inv_min)
                                : 0u;
         uint32_t incl = c;
 #pragma unroll
@@ -4757,6 +4856,7 @@ __global__ __launch_bounds__(SCAN2_THREADS, SCAN2_WAVES_PER_SIMD) void k_scan3(S
     uint32_t *tab = lds32 + (NMG ? 0 : v2p);
     uint32_t *misc = tab + 2 * a.h_slots;    // [64]
     tv.wl_lds = misc + 2 * MAX_TILE;
+    tv.tri_lds = tv.wl_lds + WL3_WORDS;
     if (tid < WL3_BUF) tv.wl_lds[tid] = tid == WL3_END ? 0xFFFFFFFFu : 0u;
     const uint32_t *gmask = a.tile_masks + (size_t)tile_rel * v2p;
     tv.gmask = reinterpret_cast<const char *>(gmask);
@@ -4789,6 +4889,7 @@ __global__ __launch_bounds__(SCAN2_THREADS, SCAN2_WAVES_PER_SIMD) void k_scan3(S
             for (uint32_t i = tid; i < a.h_slots / 2; i += SCAN2_THREADS)
                 t4[i] = make_uint4(KEY_EMPTY, 0u, KEY_EMPTY, 0u);
             if (tid < 2) misc[tid] = 0;      // [0] entries [1] overflow
+            if (tid < SCAN2_WAVES * SCAN3_GROUPS * 2) tv.tri_lds[tid] = 0;
         }
         __syncthreads();
         for (uint32_t i = tid; i < count; i += SCAN2_THREADS) {
@@ -4831,6 +4932,7 @@ __global__ __launch_bounds__(SCAN2_THREADS, SCAN2_WAVES_PER_SIMD) void k_scan3(S
         default: GFAL_RUN3(0); break;
         }
 #undef GFAL_RUN3
+        scan3_fixups<W, NMG>(a, tv, sgl, chunk, wave, tile_rel, lane, acc);
         acc.finish(tv, lane);
         cnt_good += acc.good;
         cnt_bad += acc.bad;
@@ -4914,6 +5016,7 @@ struct gfal_scorer {
     // (tile, length) and their lengths (d_t3_hdr), the cold arguments
     uint32_t *d_tile_masks = nullptr, *d_t3_hdr = nullptr, *d_tile_hdr = nullptr, *d_t3_ref = nullptr;
     size_t t3_ref_cap = 0;
+    uint32_t *d_ovh = nullptr;           // [n_items][4] k_overhang
     uint2 *d_t3_list = nullptr;
     size_t tile_masks_cap = 0, t3_hdr_cap = 0, t3_list_cap = 0, tile_hdr_cap = 0;
     Scan3Cold *d_cold = nullptr, *h_cold = nullptr;      // h_cold: pinned ring of COLD_RING structs
@@ -5052,7 +5155,7 @@ void free_scorer(gfal_scorer *s)
     void *bufs[] = {s->d_item_pairs, s->d_item_pbase, s->d_item_common, s->d_item_hdr, s->d_item_weight,
                     s->d_item_hash, s->d_item_pairs0, s->d_lids, s->d_segs,
                     s->d_rec3, s->d_item_r3, s->d_segs3, s->d_ct_rec, s->d_tile_masks, s->d_t3_hdr, s->d_t3_list,
-                    s->d_tile_hdr, s->d_cold, s->d_t3_ref,
+                    s->d_tile_hdr, s->d_cold, s->d_t3_ref, s->d_ovh,
                     s->d_len_bins, s->d_order,
                     s->d_counts_slot,
                     s->d_node_local, s->d_node_hist, s->d_item_steps, s->d_item_base,
@@ -6021,7 +6124,8 @@ static int launch_scan3(gfal_scorer *s, hipStream_t st, const Items &items, cons
     const size_t mask_bytes = (size_t)v2p * sizeof(uint32_t);
     uint32_t h_slots = 8192;
     bool nmg = !s->np_scaled;
-    const size_t fixed3 = 256 + (size_t)WL3_WORDS * 4;      // reduction words + the workgroup's pairs for the DP
+    // reduction words + the workgroup's pairs for the DP + the marks of the items that need the overhang test
+    const size_t fixed3 = 256 + (size_t)WL3_WORDS * 4 + (size_t)SCAN2_WAVES * SCAN3_GROUPS * 8;
     if (mask_bytes + (size_t)h_slots * 8 + fixed3 > (size_t)LDS_BUDGET) h_slots = 4096;
     if (mask_bytes + (size_t)h_slots * 8 + fixed3 > (size_t)LDS_BUDGET) nmg = true;
     if (const char *env = getenv("GFAL_SCAN3_NMG")) nmg = nmg || atoi(env) != 0;
@@ -6053,6 +6157,7 @@ static int launch_scan3(gfal_scorer *s, hipStream_t st, const Items &items, cons
             if ((rc = dev_reserve(&s->d_tile_hdr, &s->tile_hdr_cap, want_thdr))) return rc;
             if ((rc = dev_reserve(&s->d_t3_ref, &s->t3_ref_cap, want_ref))) return rc;
             if (!s->d_cold) {
+                HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_ovh), std::max<size_t>((size_t)s->n_items, 1) * 16));
                 HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_cold), sizeof(Scan3Cold)));
                 HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&s->h_cold), COLD_RING * sizeof(Scan3Cold),
                                       hipHostMallocDefault));
@@ -6096,6 +6201,7 @@ static int launch_scan3(gfal_scorer *s, hipStream_t st, const Items &items, cons
     a3.rec3 = s->d_rec3;
     a3.common = items.common;
     a3.item_steps = items.steps;
+    a3.ovh = s->d_ovh;
     a3.cold = s->d_cold;
     a3.tile_masks = s->d_tile_masks;
     a3.tile_hdr = s->d_tile_hdr;
@@ -6127,6 +6233,8 @@ static int launch_scan3(gfal_scorer *s, hipStream_t st, const Items &items, cons
 
     s->last_tile = tile;
     s->last_lds = (int)lds3;
+    hipLaunchKernelGGL(k_overhang, dim3((unsigned)((n_items3 + 3) / 4)), dim3(256), 0, st, items, n_items3,
+                       (const uint16_t *)s->d_images, L, s->d_ovh);
     for (int t0 = 0; t0 < n_tiles; t0 += slab_tiles) {
         const int nt = std::min(slab_tiles, n_tiles - t0);
         ta.tile0 = t0;
@@ -6148,7 +6256,7 @@ static int launch_scan3(gfal_scorer *s, hipStream_t st, const Items &items, cons
             unsigned y_total = 0;
             for (int k = 0; k < ns; ++k) {
                 const LenSeg &sg = s->segs[(size_t)(s0 + k)];
-                y_total += seg_chunks(sg.item_hi - sg.item_lo, a3.chunk_mult, a3.chunk_inv_min);
+                y_total += seg_chunks3(sg.item_hi - sg.item_lo, a3.chunk_mult, a3.chunk_inv_min);
             }
             const unsigned grid3 = (unsigned)nt * y_total;
             void *kargs[] = {&a3};
