@@ -2567,7 +2567,10 @@ __device__ __forceinline__ void add_results_by_path(const DpArgs &a, uint32_t p,
 {
     if (a.bits != nullptr && live && good) {       // search mode: remembered for the path's children
         const int slot = a.q_slot[p];
-        if (slot >= 0) atomicOr(&a.bits[(size_t)slot * a.bits_words + (pos >> 5)], 1u << (pos & 31u));
+        // (a path whose first node has a longer list than the bitmaps hold keeps none:
+        // k_child marks its slot, its children recompute)
+        if (slot >= 0 && (pos >> 5) < a.bits_words)
+            atomicOr(&a.bits[(size_t)slot * a.bits_words + (pos >> 5)], 1u << (pos & 31u));
     }
     const uint32_t prev_p = (uint32_t)__shfl_up((int)p, 1, WAVE);
     const lanemask live_mask = WAVE_MASK(live), good_mask = WAVE_MASK(good && live);
@@ -3409,9 +3412,20 @@ __global__ __launch_bounds__(CHILD_THREADS) void k_child(ChildArgs a)
     // Candidates that are not inherited are gathered in LDS and leave the workgroup
     // with ONE atomic on the list cursor (an atomic per wave and round on that one word
     // was 90 % of the first version of this kernel).
-    const bool remember = a.wl_pos != nullptr;
+    // The bitmaps are sized for the longest list of at most GFAL_BITS_MAX_LIST (4 M)
+    // entries: a path that starts on a node with a longer list (a hub in more alignments
+    // than that) keeps no bitmap and inherits nothing -- everything is recomputed for it,
+    // and its slot says so (st_bitsok == 2) to its children.
+    bool remember = a.wl_pos != nullptr;
     const int root = a.b.root[child], my_slot = a.b.slot[child];
-    const bool can_inherit = remember && root >= 0 && a.b.st_bitsok[root] != 0;
+    {
+        if (remember && a0 != STEP_NOMATCH && a0_lid != ENT_NONE) {
+            const uint32_t len0 = a.ix.inv_off[(a0_lid + 1u) * N_CLASSES] - a.ix.inv_off[a0_lid * N_CLASSES];
+            if (len0 > a.b.bits_words * 32u) remember = false;
+        }
+        if (a.wl_pos != nullptr && my_slot >= 0 && chunk == 0 && tid == 0) a.b.st_bitsok[my_slot] = remember ? 0 : 2;
+    }
+    const bool can_inherit = remember && root >= 0 && a.b.st_bitsok[root] == 1;
     // one node mask of the path's tail per DP length class: an alignment of m steps looks at
     // the last m + depth steps, its class's longest member stands in for m (4, 8, 16, 32,
     // the longest alignment): short alignments, the bulk, look at a short tail
@@ -3556,8 +3570,12 @@ __global__ __launch_bounds__(CHILD_THREADS) void k_child(ChildArgs a)
                     ncand += W ? a.items.weight[slot] : 1u;
                 }
             }
+            // every thread must take the same decision: wl_n is read between two barriers, so
+            // no wave that runs ahead into the next round can have added to it meanwhile
             __syncthreads();
-            if (wl_n > (uint32_t)(CHILD_WL_BUF - CHILD_THREADS)) flush();     // (the same for every thread)
+            const bool full = wl_n > (uint32_t)(CHILD_WL_BUF - CHILD_THREADS);
+            __syncthreads();
+            if (full) flush();
         }
     }
     flush();
@@ -3605,7 +3623,7 @@ __global__ void k_child_resolve(ChildBatch b, int n_paths, uint32_t n_empty,
         if (slot >= 0) {
             b.st_pass[slot] = pass;
             b.st_g1[slot] = g1;
-            if (b.bits_words) b.st_bitsok[slot] = 1;     // k_child + the DP kernels filled it
+            if (b.bits_words && b.st_bitsok[slot] != 2) b.st_bitsok[slot] = 1;     // k_child + the DP kernels filled it
         }
     }
     out[q] = counts[q] + (pass - g1);
@@ -6891,7 +6909,9 @@ static int build_child_index(gfal_scorer *s)
         uint32_t longest = 0;
         for (int v = 0; v + N_CLASSES <= n_loc; v += N_CLASSES) {
             const uint32_t len = off[(size_t)v + N_CLASSES] - off[(size_t)v];
-            if (len <= (4u << 20)) longest = std::max(longest, len);
+            uint32_t max_list = 4u << 20;
+            if (const char *env = getenv("GFAL_BITS_MAX_LIST")) max_list = (uint32_t)std::max(1ll, atoll(env));   // (tests)
+            if (len <= max_list) longest = std::max(longest, len);
         }
         s->bits_words = (longest + 31u) / 32u;
         if (getenv("GFAL_NO_INHERIT")) s->bits_words = 0;

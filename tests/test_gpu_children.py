@@ -142,6 +142,40 @@ def test_other_orientation_and_nodes_without_alignments(gpu):
         assert_same(res, expect(alns, full), "children")
 
 
+def test_first_node_list_longer_than_the_bitmaps(gpu, monkeypatch):
+    """GFAL_BITS_MAX_LIST caps the verdict bitmaps: a path whose first node sits in more
+    alignments than that keeps no bitmap (its children recompute, nothing is written past
+    a slot's words), paths on other first nodes go on inheriting."""
+    monkeypatch.setenv("GFAL_BITS_MAX_LIST", "96")
+    rnd = random.Random(77)
+    n_nodes, max_m = 12, 5
+    walk = [(rnd.randrange(n_nodes) << 1) | rnd.randrange(2) for _ in range(120)]
+    hub = walk[0]
+    # many alignments carry the hub node, few carry the other roots' first nodes
+    alns = walk_alignments(rnd, walk, n_nodes, 2500, max_m)
+    alns += [[walk[3], hub, walk[1]][:rnd.randint(2, 3)] for _ in range(400)]
+    aoff, ast = csr(alns)
+    with Scorer(aoff, ast, n_nodes + 2) as sc, Group([sc]) as g:
+        tree = Tree(g, 300)
+        roots = [walk[0:max_m + 1], walk[7:7 + max_m + 2], walk[20:20 + max_m + 1]]
+        slots, res = tree.store(roots)
+        assert_same(res, expect(alns, roots), "stored roots")
+        frontier = [(s, list(p)) for s, p in zip(slots, roots)]
+        for rnd_no in range(5):
+            batch = []
+            for s, p in frontier:
+                i = (walk.index(p[-1]) + 1) % len(walk)
+                for st in {walk[i], hub, p[-1] ^ 1}:
+                    batch.append((("slot", s), st))
+            chain_from = 0
+            for d in range(3):
+                batch.append((("batch", chain_from), walk[(5 * d + rnd_no) % len(walk)]))
+                chain_from = len(batch) - 1
+            slot, full, res = tree.children(batch)
+            assert_same(res, expect(alns, full), "round %d" % rnd_no)
+            frontier = [(slot[k], full[k]) for k in range(0, len(full), 3)][:5]
+
+
 @pytest.mark.parametrize("dedup", [False, True])
 def test_shards_and_dedup(gpu, dedup):
     """Two shards of one set on one device (counters added on the host) and the
