@@ -6,10 +6,12 @@
 One "step" = one pass of the hot path over one batch: every candidate path of
 the workload scored against every alignment (reference src/eval.cpp:67-108 once
 per candidate), with alignments, candidates and counters resident in HBM when
-the timed region starts.  N > 1 (launched by torch.distributed.run, one rank
-per GPU): the alignments are sharded over the ranks, every rank scores the whole
-batch against its shard, and the per-path counters are summed with one RCCL
-all-reduce inside the step -- the same total work for every N ("strong").
+the timed region starts.  N > 1: one rank per GPU -- started by
+torch.distributed.run, or, when WORLD_SIZE is not set, by this script itself
+(`python bench.py --gpus N` spawns its N rank processes before anything touches
+a GPU) -- the alignments are sharded over the ranks, every rank scores the
+whole batch against its shard, and the per-path counters are summed with one
+RCCL all-reduce inside the step: the same total work for every N ("strong").
 
 Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for how `roofline`,
 `cpu_baseline` and `search_mode` are defined.
@@ -26,6 +28,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+# the same guide: a SIMD issues one wave64 VALU instruction per 2 cycles (4 x SIMD-32 ... 64 lanes in two
+# passes), 1024 SIMDs, 2.4 GHz -> 1228.8 G wave-instructions/s chip-wide
+VALU_PEAK_GINST = 1024 * 2.4 / 2.0
+L2_PEAK_GBS = 34500.0   # aggregate L2 read bandwidth (4 MiB per XCD), same guide
 
 
 def _load_json(name):
@@ -76,14 +82,22 @@ def search_mode(t, device):
             stdout[key] = p.stdout
             m1 = re.search(r"search ([0-9.]+) s \(candidates ([0-9.]+) s, scoring ([0-9.]+) s", p.stderr)
             m2 = re.search(r"scored (\d+) candidate paths in (\d+) batches, (\d+) of them in full", p.stderr)
+            m3 = re.search(r"needed (\d+) of the scored candidates", p.stderr)
             if m1 and m2:
                 scored, nb = int(m2.group(1)), int(m2.group(2))
+                needed = int(m3.group(1)) if m3 else None
                 out[key] = {"command": "gfalign search -m 20000 (default speculation; GAF parse and scorer "
                                        "creation not counted)" + (" GFALIGN_INCREMENTAL=0" if env else ""),
                             "scored_paths": scored, "scored_in_full": int(m2.group(3)), "batches": nb,
                             "search_loop_s": float(m1.group(1)), "candidates_s": float(m1.group(2)),
                             "scoring_s": float(m1.group(3)), "process_wall_s": wall,
-                            "paths_per_s": scored / float(m1.group(1))}
+                            "paths_per_s": scored / float(m1.group(1)),
+                            # the candidates whose scores the search went on to use (extensions of popped
+                            # entries = the reference's evaluatePath calls, src/eval.cpp:146-162); the rest
+                            # of scored_paths is speculation that was never popped
+                            "needed_paths": needed,
+                            "needed_paths_per_s": (needed / float(m1.group(1))) if needed else None,
+                            "speculation_waste": (1.0 - needed / scored) if needed and scored else None}
         if stdout["cli"] != stdout["cli_full"]:
             sys.exit("PARITY FAILURE: gfalign search prints different rows with and without GFALIGN_INCREMENTAL")
         raw = np.fromfile(dump, dtype=np.int32)
@@ -203,28 +217,69 @@ def cpu_fast(t, bad, good, una, n_paths=64):
                       "quantiles) x all %d alignments of %s; every fourth of them on one core" % (n_paths, t.N, t.name)}
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: N fresh rank processes of this very
+    script (children, never a re-exec; the parent has not imported torch or touched a GPU),
+    one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as torch.distributed.run
+    would.  Rank 0's output is ours; any rank failing fails the run."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    # a rank that dies leaves the others waiting at a rendezvous or a collective: end them
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            if p.poll() not in (None, 0):
+                failed = r
+        if procs[0].poll() is not None and all(p.poll() is not None for p in procs[1:]):
+            break
+        time.sleep(0.2)
+    if failed is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    out0 = procs[0].stdout.read() if procs[0].stdout else ""
+    codes = [p.wait() for p in procs]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    if any(codes):
+        sys.exit("bench.py: rank exit codes %s" % codes)
+    sys.exit(0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="config3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-search-mode", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)          # (does not return)
+
     import torch
     import torch.distributed as dist
     from gfalign_amd import shard, synth
-    from gfalign_amd.scorer import Scorer
+    from gfalign_amd.scorer import Scorer, load_library
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run "
-                     "(one rank per GPU)" % args.gpus)
+        sys.exit("bench.py --gpus %d started with WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no CPU fallback on the product path)")
     # Rehearsal on a one-GPU box (GFALIGN_BENCH_REHEARSAL=1): every rank uses
@@ -299,37 +354,47 @@ def main():
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = P * args.steps / elapsed
-        # Dominant kernels: the scan (k_scan2, plus k_scan for the rare alignment
-        # lengths), timed live with HIP events on the caller's stream around every
-        # launch of the timed region (gfal_scorer_set_profiling).
+        # Dominant kernel: k_scan3, the walk over every alignment for every tile of 31
+        # candidate paths, timed live with HIP events on the caller's
+        # stream around its launches of the timed region (gfal_scorer_set_profiling).
         #
-        # Roofline.  The scan re-uses every alignment load for all paths of a tile
-        # out of LDS and the alignment set lives in L2 / Infinity Cache: it moves
-        # ~0.5 % of its algorithmic bytes through HBM, so HBM bandwidth does not
-        # bound it.  What bounds it is instruction issue on the 1024 SIMDs:
-        #   achieved = VALU wave-instructions of one step (SQ_INSTS_VALU of the scan
-        #              kernels, rocprofv3 PMC pass committed under profiles/) / the
-        #              live scan time,
-        #   peak     = the best sustained VALU issue rate measured on this chip by
-        #              tools/valu_rate.hip (simple 2-operand integer ops; the kernel's
-        #              3-operand / compare / readlane ops issue at ~60 % of that).
-        # The algorithmic-bytes figure of SURVEY.md 8(d) and the physical HBM traffic
-        # stay in the object as `hbm_*` fields.
+        # Roofline.  SURVEY.md 8(d)'s algorithmic bytes (the alignment set re-read per
+        # candidate) divided by the kernel time exceed the HBM peak many times over: a
+        # tile of paths shares every load and the set lives in L2 / Infinity Cache, so
+        # HBM does not bound the kernel (hbm_* fields, PMC traffic).  What bounds an
+        # integer compare-and-count kernel is instruction issue:
+        #   achieved = VALU wave-instructions k_scan3 issues per step (SQ_INSTS_VALU, rocprofv3
+        #              PMC pass, profiles/issue_<workload>.json) / the live kernel time,
+        #   peak     = one wave64 VALU instruction per 2 cycles per SIMD (the guide),
+        #   useful   = the same without the instructions of a prologue-only run
+        #              (GFAL_DEBUG_SCAN2=1 PMC pass): the item loop's share.
+        # The counters are tied to the build they were taken on: another library build
+        # id -> the fractions are null rather than stale.
         S_r, N_r = int(info["n_steps"]), int(info["n_aln"])
         alg_bytes = P * (4 * S_r + 4 * (N_r + 1) + 12) + 4 * total_steps
-        scan_s = info["scan_ms"] * 1e-3
-        alg_gbs = alg_bytes / scan_s / 1e9 if scan_s > 0 else None
+        kernel_ms = info["scan_kernel_ms"] if info["scan_kernel_ms"] > 0 else info["scan_ms"]
+        kernel_s = kernel_ms * 1e-3
+        alg_gbs = alg_bytes / kernel_s / 1e9 if kernel_s > 0 else None
+        lib_id = load_library().gfal_build_id().decode()
         traffic = issue = None
+        note_counters = None
         peaks = _load_json("issue_peaks.json")
         if world == 1:
-            tr = _load_json("traffic_%s.json" % args.workload)
-            traffic = tr.get("hbm_bytes_per_launch") if tr else None
             issue = _load_json("issue_%s.json" % args.workload)
-        achieved = peak = frac = None
-        if issue and peaks and scan_s > 0:
-            achieved = issue["valu_wave_insts_per_step"] / scan_s / 1e9           # G wave-inst/s, whole chip
-            peak = peaks["valu_vop2_ginst_per_s_simd"] * peaks["n_simds"]
-            frac = achieved / peak
+            tr = _load_json("traffic_%s.json" % args.workload)
+            if issue and issue.get("build_id") != lib_id:
+                note_counters = ("profiles/issue_%s.json was taken on build %s, this library is %s: "
+                                 "instruction-issue figures withheld" % (args.workload, issue.get("build_id"), lib_id))
+                issue = None
+            if tr and tr.get("build_id") == lib_id:
+                traffic = tr.get("hbm_bytes_per_launch")
+        achieved = frac = useful = frac_useful = None
+        if issue and kernel_s > 0:
+            achieved = issue["valu_wave_insts_per_step"] / kernel_s / 1e9           # G wave-inst/s, whole chip
+            frac = achieved / VALU_PEAK_GINST
+            if issue.get("useful_valu_wave_insts_per_step") is not None:
+                useful = issue["useful_valu_wave_insts_per_step"] / kernel_s / 1e9
+                frac_useful = useful / VALU_PEAK_GINST
         out = {
             "metric": "candidate paths scored/sec in search mode",
             "value": value,
@@ -347,39 +412,47 @@ def main():
                 "workload": "%s: synthetic %d-node tangle, %d GAF alignments (S=%d steps), "
                             "%d candidate paths, filter on" % (args.workload, t.V, t.N, t.S, P),
                 "parallelism": "alignments sharded over %d GPU(s), all-reduce of int32[3P]" % world,
+                "note": "value = the full evaluation of a 10 000-path batch (the reference's evaluatePath per "
+                        "candidate); the search itself: search_mode.cli",
                 "tile_paths": info["tile_paths"],
                 "workgroups": info["n_workgroups"],
                 "dp_pairs_per_step": info["dp_pairs"],
             },
             "roofline": {
                 "bound": "valu-issue",
-                "kernel": "k_scan2 (one launch per alignment-length group, side by side) + k_scan (rare lengths): span from the first start to the last end",
+                "kernel": "k_scan3 (every alignment against every tile of 31 candidate paths)",
                 "achieved": achieved,
-                "peak": peak,
+                "peak": VALU_PEAK_GINST,
                 "unit": "G wave-instructions/s",
                 "frac": frac,
                 "traffic": traffic,
-                "kernel_ms": info["scan_ms"],
+                "kernel_ms": kernel_ms,
+                "useful_achieved": useful,
+                "frac_useful": frac_useful,
+                "valu_wave_insts_per_step": issue["valu_wave_insts_per_step"] if issue else None,
+                "useful_valu_wave_insts_per_step": issue.get("useful_valu_wave_insts_per_step") if issue else None,
+                "salu_wave_insts_per_step": issue["salu_wave_insts_per_step"] if issue else None,
+                "counters_build_id": issue.get("build_id") if issue else None,
+                "library_build_id": lib_id,
+                "counters_note": note_counters,
+                # the phases of a step (HIP events): window preparation + scan kernels, exact DP, whole call
+                "scan_phase_ms": info["scan_ms"],
                 "dp_kernel_ms": info["dp_ms"],
                 "call_ms": info["total_ms"],
-                "valu_wave_insts_per_step": issue["valu_wave_insts_per_step"] if issue else None,
-                "salu_wave_insts_per_step": issue["salu_wave_insts_per_step"] if issue else None,
-                "peak_vop3_class": (peaks["valu_vop3_ginst_per_s_simd"] * peaks["n_simds"]) if peaks else None,
-                # the same against the measured rate of a synthetic loop with the scan's own mix
-                # (4 VALU : 2 SALU : 1/8 LDS, tools/valu_rate.hip): how close the kernel is to what
-                # its instruction mix can issue at all; `frac` above is against simple two-operand ops
-                "peak_scan_mix": (peaks["valu_scan_mix_ginst_per_s_simd"] * peaks["n_simds"]) if peaks else None,
-                "frac_of_scan_mix_peak": (achieved / (peaks["valu_scan_mix_ginst_per_s_simd"] * peaks["n_simds"]))
-                                         if (achieved and peaks) else None,
+                # measured on this chip (tools/valu_rate.hip): simple two-operand ops / three-operand,
+                # compare-to-SGPR, readlane class -- what the guide's 2-cycle figure becomes in practice
+                "peak_measured_vop2": (peaks["valu_vop2_ginst_per_s_simd"] * peaks["n_simds"]) if peaks else None,
+                "peak_measured_vop3_class": (peaks["valu_vop3_ginst_per_s_simd"] * peaks["n_simds"]) if peaks else None,
                 "hbm_algorithmic_bytes_per_launch": alg_bytes,
                 "hbm_algorithmic_gbs": alg_gbs,
                 "hbm_algorithmic_frac_of_8tbs": (alg_gbs / HBM_PEAK_GBS) if alg_gbs else None,
-                "hbm_physical_gbs": (traffic / scan_s / 1e9) if traffic and scan_s > 0 else None,
-                "note": "not HBM-bound: the scan moves ~0.5 % of its algorithmic bytes (SURVEY.md 8(d): the "
-                        "alignment set re-read per candidate) through HBM -- tiles of candidate paths share "
-                        "each load from LDS, the set sits in L2 / Infinity Cache -- so the algorithmic rate "
-                        "exceeds the HBM peak and says nothing about the binding unit, which is SIMD "
-                        "instruction issue; counters and measured peaks: profiles/ (DESIGN.md section 5)",
+                "hbm_physical_gbs": (traffic / kernel_s / 1e9) if traffic and kernel_s > 0 else None,
+                "hbm_physical_frac_of_8tbs": (traffic / kernel_s / 1e9 / HBM_PEAK_GBS) if traffic and kernel_s > 0 else None,
+                "note": "not HBM-bound: the kernel moves a fraction of a percent of its algorithmic bytes "
+                        "(SURVEY.md 8(d): the alignment set re-read per candidate) through HBM -- 31 candidate "
+                        "paths share each load, the set sits in L2 / Infinity Cache -- so the algorithmic rate "
+                        "exceeds the HBM peak and says nothing about the binding unit, which is instruction "
+                        "issue; counters: profiles/ (DESIGN.md section 5)",
             },
         }
         out["config"]["counter_checksum"] = int(bad.astype(np.uint64).sum() * 3 +

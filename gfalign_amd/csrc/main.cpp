@@ -729,6 +729,9 @@ int main(int argc, char **argv)
                     (unsigned long long)search.batches(), (unsigned long long)search.scored_in_full(),
                     (unsigned long long)scorer.dp_pairs(),
                     (unsigned long long)search.prefetch_hits(), (unsigned long long)search.prefetch_misses());
+        if (verbose_flag)
+            fprintf(stderr, "needed %llu of the scored candidates (extensions of popped entries: the reference's "
+                            "evaluatePath calls)\n", (unsigned long long)search.needed_paths());
         return rc;
     }
     case 4: return run_filter(o, recs, totals);

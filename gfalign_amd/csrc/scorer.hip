@@ -5125,7 +5125,8 @@ struct gfal_scorer {
     // kept in a ring and averaged by gfal_scorer_get_info
     static constexpr int EV_RING = 128;
     bool profiling = false;
-    hipEvent_t ev[EV_RING][4] = {};
+    hipEvent_t ev[EV_RING][6] = {};      // [4], [5]: around the dominant scan kernel (k_scan3)
+    bool ev_scan3 = false;               // the last profiled call recorded them
     int ev_calls = 0;   // calls recorded since profiling was switched on
 };
 
@@ -6131,7 +6132,7 @@ constexpr int COLD_RING = 64;
 static int launch_scan3(gfal_scorer *s, hipStream_t st, const Items &items, const ImageLayout &L,
                         int32_t n_paths, int32_t max_path_len, int filter, int n_segs, int n_items3,
                         int want_groups, int slots, uint32_t *d_counts, unsigned long long *wl_count,
-                        uint32_t *d_hist)
+                        uint32_t *d_hist, hipEvent_t *ev)
 {
     const int tile = std::max(1, std::min(T3_MAX, (int)n_paths));
     const int n_tiles = (n_paths + tile - 1) / tile;
@@ -6266,6 +6267,9 @@ static int launch_scan3(gfal_scorer *s, hipStream_t st, const Items &items, cons
         HIP_TRY(hipGetLastError());
         a3.tile0 = t0;
         a3.n_tiles = nt;
+        // (profiling: the dominant kernel by itself, when the batch is one slab)
+        const bool time_it = ev != nullptr && slab_tiles >= n_tiles;
+        if (time_it) HIP_TRY(hipEventRecord(ev[4], st));
         for (int s0 = 0; s0 < n_segs; s0 += MAX_SEGS) {
             const int ns = std::min(MAX_SEGS, n_segs - s0);
             a3.segs = s->d_segs3 + s0;
@@ -6281,6 +6285,10 @@ static int launch_scan3(gfal_scorer *s, hipStream_t st, const Items &items, cons
             HIP_TRY(hipLaunchKernel(scan3_kernel(s->d_item_weight != nullptr, nmg), dim3(grid3),
                                     dim3(SCAN2_THREADS), kargs, lds3, st));
             s->last_grid += (int)grid3;
+        }
+        if (time_it) {
+            HIP_TRY(hipEventRecord(ev[5], st));
+            s->ev_scan3 = true;
         }
     }
     return GFAL_OK;
@@ -6365,7 +6373,10 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
         HIP_TRY(hipMemsetAsync(s->d_status, 0, 8 * sizeof(uint32_t), st));
     }
     hipEvent_t *ev = s->ev[s->ev_calls % gfal_scorer::EV_RING];
-    if (s->profiling) HIP_TRY(hipEventRecord(ev[0], st));
+    if (s->profiling) {
+        HIP_TRY(hipEventRecord(ev[0], st));
+        s->ev_scan3 = false;
+    }
 
     const size_t prep_lds = img_bytes + (size_t)L.nm * sizeof(uint16_t) +
                             (size_t)L.v2 * sizeof(uint32_t);
@@ -6478,7 +6489,8 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
         const bool use3 = n_segs2 > 0 && !children && s->scan_mode != 2;
         if (use3) {
             const int rc3 = launch_scan3(s, st, items, L, n_paths, max_path_len, filter, n_segs2, item_lo_chain,
-                                         want_groups, slots, d_counts, wl_count, d_hist);
+                                         want_groups, slots, d_counts, wl_count, d_hist,
+                                         s->profiling ? ev : nullptr);
             if (rc3) return rc3;
         }
         if (n_segs2 > 0 && !children && !use3) {
@@ -7706,11 +7718,15 @@ int gfal_scorer_get_info(gfal_scorer *s, gfal_info *out)
 #endif
         if (s->profiling && s->ev_calls > 0) {
             const int n = std::min(s->ev_calls, (int)gfal_scorer::EV_RING);
-            double scan = 0, dp = 0, total = 0;
+            double scan = 0, dp = 0, total = 0, scan3 = 0;
             for (int i = 0; i < n; ++i) {
                 hipEvent_t *ev = s->ev[i];
                 float t = 0.f;
                 HIP_TRY(hipEventSynchronize(ev[3]));
+                if (s->ev_scan3) {
+                    HIP_TRY(hipEventElapsedTime(&t, ev[4], ev[5]));
+                    scan3 += t;
+                }
                 HIP_TRY(hipEventElapsedTime(&t, ev[1], ev[2]));
                 scan += t;
                 HIP_TRY(hipEventElapsedTime(&t, ev[2], ev[3]));
@@ -7719,6 +7735,7 @@ int gfal_scorer_get_info(gfal_scorer *s, gfal_info *out)
                 total += t;
             }
             out->scan_ms = (float)(scan / n);
+            out->scan_kernel_ms = (float)(scan3 / n);
             out->dp_ms = (float)(dp / n);
             out->total_ms = (float)(total / n);
             out->profiled_calls = n;

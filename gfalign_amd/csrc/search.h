@@ -417,6 +417,7 @@ public:
             if (!queue_.begin()->second->kids_scored && !score_front()) return EXIT_FAILURE;
             std::unique_ptr<Node> u = std::move(queue_.begin()->second);    // :135
             queue_.erase(queue_.begin());
+            needed_ += u->kids.size();      // (the reference's evaluatePath calls, :162)
             for (std::unique_ptr<Node> &c : u->kids) {                      // :136-185
                 const int32_t alt =
                     (int32_t)c->bad - (int32_t)c->good - (int32_t)c->uniques;   // :163
@@ -449,6 +450,10 @@ public:
     }
 
     uint64_t scored_paths() const { return scored_; }
+    // candidates whose scores the search went on to use: the extensions of the entries it
+    // popped (one evaluatePath call each in the reference, src/eval.cpp:146-162); the rest
+    // of scored_paths() was speculation that was never popped
+    uint64_t needed_paths() const { return needed_; }
     uint64_t scored_in_full() const { return incr_ ? full_scored_ : scored_; }
     uint64_t batches() const { return batches_; }
     uint64_t prefetch_hits() const { return prefetch_hits_; }
@@ -762,7 +767,7 @@ private:
     std::vector<int> record_of_;
     std::vector<uint32_t> allowance_;
     std::map<Key, std::unique_ptr<Node>> queue_;
-    uint64_t seq_ = 0, scored_ = 0, batches_ = 0;
+    uint64_t seq_ = 0, scored_ = 0, batches_ = 0, needed_ = 0;
     double t_collect_ = 0, t_score_ = 0, t_ahead_ = 0;
     uint64_t made_ahead_ = 0;
     // the batch being collected, and the parents of the one the devices are scoring

@@ -28,7 +28,8 @@ class GfalInfo(ctypes.Structure):
                 ("dp_ms", ctypes.c_float), ("total_ms", ctypes.c_float),
                 ("profiled_calls", ctypes.c_int32), ("n_lanes", ctypes.c_int64),
                 ("n_score_calls", ctypes.c_int64), ("n_device_passes", ctypes.c_int64),
-                ("n_overflow_reruns", ctypes.c_int64), ("wl_capacity", ctypes.c_int64)]
+                ("n_overflow_reruns", ctypes.c_int64), ("wl_capacity", ctypes.c_int64),
+                ("scan_kernel_ms", ctypes.c_float), ("reserved_", ctypes.c_int32)]
 
 
 # every symbol include/gfalign_scorer.h declares

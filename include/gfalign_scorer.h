@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define GFAL_ABI_VERSION 3
+#define GFAL_ABI_VERSION 4
 
 /* include/alignments.h:246 (MAX_N 1001): longest path / alignment accepted. */
 #define GFAL_MAX_STEPS 1000
@@ -288,6 +288,11 @@ typedef struct {
                                 short (the list grows to fit: once per scorer
                                 and batch shape)                               */
     int64_t  wl_capacity;    /* exact-DP worklist entries (grows on overflow)  */
+    float    scan_kernel_ms; /* of scan_ms: the dominant kernel alone (k_scan3:
+                                the alignment walk itself, without the per-tile
+                                window preparation); 0 when it was not timed
+                                (k_scan / k_scan2 only, or a batch in slabs)   */
+    int32_t  reserved_;
 } gfal_info;
 
 /* Record HIP events (on the caller's stream) around the kernels of each score

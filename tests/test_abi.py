@@ -35,7 +35,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_abi_version_and_strerror(lib):
-    assert lib.gfal_abi_version() == 3
+    assert lib.gfal_abi_version() == 4
     assert lib.gfal_strerror(0) == b"ok"
     assert b"device" in lib.gfal_strerror(-3)
 
