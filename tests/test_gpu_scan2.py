@@ -1,14 +1,19 @@
-"""GPU parity of the two scan kernels.
+"""GPU parity of the scan kernels.
 
 k_scan   walks occurrence chains per (item, tile path); it keeps the rare
          alignment lengths and the batches of a few dozen paths.
-k_scan2  answers the subpath test for all tile paths at once from a hashed
-         window table per (tile, alignment length).
+k_scan2  (round 2) answers the subpath test for all 8 paths of a tile at once from
+         a hashed window table per (tile, alignment length).
+k_scan3  (round 3, the default) does it for 31 paths by content identity: k_tile
+         looks the tile's windows up in the scorer's content table, k_scan3 probes
+         a table of content indices (k_tile_masks, k_overhang beside them).
 
-`GFAL_SCAN=1` / `=2` force one kernel for everything, `GFAL_HASH_MIN_ITEMS=1`
-makes every length a k_scan2 segment in the automatic mode; every case below is
-compared bit for bit with the oracle (reference src/eval.cpp:67-108 restated)
-under each of them.  The reference has no fixture for this path beyond
+`GFAL_SCAN=1` / `=2` / `=3` force one kernel for everything, `GFAL_HASH_MIN_ITEMS=1`
+makes every length a k_scan3 segment in the automatic mode, `GFAL_SCAN3_NMG=1`
+keeps k_scan3's node masks in HBM (what a tangle of many nodes does by itself),
+`GFAL_SCAN3_SLOTS=4096` halves its table (more passes over unrelated paths); every
+case below is compared bit for bit with the oracle (reference src/eval.cpp:67-108
+restated) under each of them.  The reference has no fixture for this path beyond
 tests/golden (parity unpinned): the oracle is the checker.
 """
 import random
@@ -22,7 +27,8 @@ from helpers import csr, random_case, walk_case
 
 pytestmark = pytest.mark.gpu
 
-MODES = [{"GFAL_SCAN": "1"}, {"GFAL_SCAN": "2"}, {"GFAL_HASH_MIN_ITEMS": "1"}, {}]
+MODES = [{"GFAL_SCAN": "1"}, {"GFAL_SCAN": "2"}, {"GFAL_SCAN": "3"}, {"GFAL_HASH_MIN_ITEMS": "1"}, {},
+         {"GFAL_SCAN": "3", "GFAL_SCAN3_NMG": "1"}, {"GFAL_SCAN": "3", "GFAL_SCAN3_SLOTS": "4096"}]
 
 
 @pytest.fixture(scope="module")
@@ -59,6 +65,45 @@ def test_every_length_in_both_kernels(gpu, monkeypatch, seed):
     rnd = random.Random(seed)
     alns, paths = walk_case(rnd, 30, 160, 5000, 120, 40)
     check_modes(monkeypatch, alns, paths, 32)
+
+
+def test_very_long_alignments(gpu, monkeypatch):
+    """Alignments of 100..220 steps: beyond what k_tile counts as a run of agreeing
+    positions (127), so every path enters such windows itself; the reference path's
+    indices stop at 16 steps; the overhang test of such pairs is done pair by pair."""
+    rnd = random.Random(15)
+    n_nodes = 50
+    walk = [(rnd.randrange(n_nodes) << 1) | rnd.randrange(2) for _ in range(700)]
+    paths = [walk[:rnd.randint(230, 700)] for _ in range(70)]
+    for p in paths[::7]:
+        p[rnd.randrange(0, 200)] = (rnd.randrange(n_nodes) << 1) | rnd.randrange(2)
+    alns = []
+    for _ in range(3000):
+        m = rnd.choice((100, 126, 127, 128, 129, 180, 220))
+        s0 = rnd.randrange(0, 700 - m)
+        b = list(walk[s0:s0 + m])
+        if rnd.random() < 0.3:
+            b[rnd.randrange(m)] = (rnd.randrange(n_nodes) << 1) | rnd.randrange(2)
+        if rnd.random() < 0.5:
+            b = [x ^ 1 for x in reversed(b)]
+        alns.append(b)
+    check_modes(monkeypatch, alns, paths, n_nodes, filters=(True,))
+
+
+def test_tile_boundaries(gpu, monkeypatch):
+    """1, 2, 31, 32, 33, 62, 63 and 97 paths: tiles of 31 with a short last one."""
+    rnd = random.Random(16)
+    alns, paths = walk_case(rnd, 25, 120, 4000, 97, 9)
+    aoff, ast = csr(alns)
+    monkeypatch.setenv("GFAL_SCAN", "3")
+    with Scorer(aoff, ast, 32) as sc:
+        for n in (1, 2, 31, 32, 33, 62, 63, 97):
+            poff, pst = csr(paths[:n])
+            for f in (True, False):
+                got = sc.evaluate_paths(poff, pst, f)
+                exp = oracle.evaluate_paths(aoff, ast, poff, pst, f)
+                for name, g, e in zip(("bad", "good", "unaligned"), got, exp):
+                    assert np.array_equal(g, e), (n, f, name)
 
 
 def test_tiny_alphabet_overhangs(gpu, monkeypatch):
@@ -134,28 +179,29 @@ def test_tiles_whose_paths_start_differently(gpu, monkeypatch):
     check_modes(monkeypatch, alns, paths, 8)
 
 
-def test_dedup_and_shards_through_k_scan2(gpu, monkeypatch):
+def test_dedup_and_shards_through_k_scan2_and_k_scan3(gpu, monkeypatch):
     """Weighted lanes (gfal_scorer_create_dedup) and a 3-way sharded set give
-    the counters of the plain scorer under k_scan2 as well."""
+    the counters of the plain scorer under k_scan2 and k_scan3 as well."""
     rnd = random.Random(61)
     alns, paths = walk_case(rnd, 20, 100, 6000, 110, 10)
     alns = alns + alns[:2000] + alns[:500]                 # copies: weights up to 3
     aoff, ast = csr(alns)
     poff, pst = csr(paths)
     exp = oracle.evaluate_paths(aoff, ast, poff, pst, True)
-    monkeypatch.setenv("GFAL_SCAN", "2")
-    with Scorer(aoff, ast, 32, dedup=True) as sc:
-        got = sc.evaluate_paths(poff, pst, True)
-        assert sc.info()["n_lanes"] < len(alns)
-    for g, e in zip(got, exp):
-        assert np.array_equal(g, e)
-    acc = [np.zeros(len(paths), np.uint64) for _ in range(3)]
-    for k in range(3):
-        with Scorer(aoff, ast, 32, shard=(k, 3)) as sc:
-            for a, part in zip(acc, sc.evaluate_paths(poff, pst, True)):
-                a += part
-    for a, e in zip(acc, exp):
-        assert np.array_equal(a, e.astype(np.uint64))
+    for mode in ("2", "3"):
+        monkeypatch.setenv("GFAL_SCAN", mode)
+        with Scorer(aoff, ast, 32, dedup=True) as sc:
+            got = sc.evaluate_paths(poff, pst, True)
+            assert sc.info()["n_lanes"] < len(alns)
+        for g, e in zip(got, exp):
+            assert np.array_equal(g, e)
+        acc = [np.zeros(len(paths), np.uint64) for _ in range(3)]
+        for k in range(3):
+            with Scorer(aoff, ast, 32, shard=(k, 3)) as sc:
+                for a, part in zip(acc, sc.evaluate_paths(poff, pst, True)):
+                    a += part
+        for a, e in zip(acc, exp):
+            assert np.array_equal(a, e.astype(np.uint64))
 
 
 @pytest.mark.parametrize("n_nodes", [15000, 24000])
