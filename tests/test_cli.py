@@ -313,6 +313,53 @@ def test_config5_flow_search_then_eval_path(cli, gpu, tmp_path):
     assert int(best[2]) <= int(good[0]) + int(bad[0])
 
 
+@pytest.mark.gpu
+def test_config5_flow_at_size(cli, gpu, tmp_path):
+    """The config-5 shape on the box: a 5 000-node tangle, 300 000 alignments, `search -m
+    1000000000` bounded by a node list of the walk's first nodes (the queue runs empty),
+    alignments sharded over two scorers; the rows must not depend on how candidates are
+    scored (from their parents, the default, or every one in full), and `evalPath` on the
+    best path must print the oracle's score for every one of the 300 000 alignments."""
+    import numpy as np
+    import oracle
+    t = synth.Tangle(V=5000, n_T=1000, N=300000, P=1, seed=33)
+    d = str(tmp_path)
+    t.write_gfa(d + "/g.gfa")
+    t.write_gaf(d + "/a.gaf")
+    K = 28                                     # the search may only walk the truth walk's first steps
+    head = [int(x) >> 1 for x in t.T[:K]]
+    with open(d + "/nodes.tsv", "w") as f:
+        for node in dict.fromkeys(head):
+            f.write("utig4-%d\t%d\n" % (node, head.count(node)))
+    src, dst = "utig4-%d" % head[0], "utig4-%d" % head[-1]
+    base = ["search", "-f", d + "/g.gfa", "-g", d + "/a.gaf", "-n", d + "/nodes.tsv", "-s", src, "-d", dst,
+            "-m", "1000000000", "--devices", "2", "--verbose"]
+    outs = []
+    for env in ({"GFALIGN_SHARE_DEVICE": "1"}, {"GFALIGN_SHARE_DEVICE": "1", "GFALIGN_INCREMENTAL": "0"}):
+        rc, out, err = run(cli, base, env=env)
+        assert rc == 0, err[-2000:]
+        outs.append(out)
+        assert "Reached maximum" not in out
+    assert outs[0] == outs[1] and outs[0].count("\n") >= 1
+    best = outs[0].splitlines()[-1].split("\t")
+    assert int(best[2]) > 0                    # non-zero good counter
+    path_text = best[7]
+    rc, out, err = run(cli, ["evalPath", "-f", d + "/g.gfa", "-g", d + "/a.gaf", "-p", path_text, "--devices", "2"],
+                       env={"GFALIGN_SHARE_DEVICE": "1"})
+    assert rc == 0, err[-2000:]
+    lines = out.splitlines()
+    assert lines[0] == path_text and len(lines) == t.N + 2
+    ids = {"utig4-%d" % k: k for k in range(t.V)}
+    path = [(ids[c[:-1]] << 1) | int(c[-1] == "-") for c in path_text.split(",")]
+    fw, rcs = oracle.pair_scores(t.aln_off, t.aln_steps, path)
+    got_scores = np.array([int(l.rsplit("\t", 1)[1]) for l in lines[1:-1]])
+    assert np.array_equal(got_scores, np.maximum(fw, rcs))
+    bad, good, _ = oracle.evaluate_paths(t.aln_off, t.aln_steps, [0, len(path)], path, False)
+    uniques = len(set(x >> 1 for x in path))
+    assert lines[-1] == "%d\t%d\t%d\t%d\t%d" % (bad[0], good[0], int(bad[0]) - int(good[0]) - uniques,
+                                                 len(path), uniques)
+
+
 # ---- CLI behaviours of the reference beyond its .tst files (CPU) ----
 
 def test_graph_statistics_is_refused_not_ignored(cli):
