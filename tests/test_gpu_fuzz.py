@@ -28,10 +28,12 @@ def _seed():
     return int(os.environ.get("GFALIGN_FUZZ_SEED", int(time.time()) % 1000000))
 
 
-@pytest.mark.parametrize("script,cases", [("fuzz_gpu.py", 60), ("fuzz_children.py", 30)])
-def test_fresh_random_cases(gpu, script, cases):
+@pytest.mark.parametrize("script,cases,env", [("fuzz_gpu.py", 50, {}), ("fuzz_gpu.py", 40, {"GFAL_SCAN": "3"}),
+                                              ("fuzz_children.py", 30, {})])
+def test_fresh_random_cases(gpu, script, cases, env):
+    """(GFAL_SCAN=3: k_tile / k_scan3 also for the small batches that k_scan would take)"""
     seed = _seed()
     p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", script), str(cases), str(seed)],
-                       cwd=ROOT, capture_output=True, text=True, timeout=900)
+                       cwd=ROOT, env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, "seed0 %d\n%s\n%s" % (seed, p.stdout[-3000:], p.stderr[-2000:])
     assert "OK:" in p.stdout
