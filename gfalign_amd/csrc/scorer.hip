@@ -4224,7 +4224,8 @@ __global__ __launch_bounds__(1024) void k_tile(TileArgs a)
             if (!((w >> i) & 1u)) nz = 32 * j + i;
             const int r = min(nz - (32 * j + i), T3_RUN_CAP);
             run[(size_t)(32 * j + i) * 32 + q] = (uint8_t)r;
-            if (32 * j + i < n_t && r < max_m) own |= 1u << i;
+            // (a window of its own: longer than the run, and still inside the path)
+            if (32 * j + i < n_t && r < max_m && r < n_t - (32 * j + i)) own |= 1u << i;
         }
         if (own && a.debug != 3) {
             const uint32_t k = (uint32_t)__builtin_popcount(own);
@@ -4267,7 +4268,7 @@ __global__ __launch_bounds__(1024) void k_tile(TileArgs a)
             const int f = 32 * j + i;
             if (f >= n_t) break;
             const int r = run[(size_t)f * 32 + q];
-            if (r >= max_m) continue;
+            if (r >= max_m || r >= n_t - f) continue;
             t3_windows_at(a, Fp, f, n_t, r + 1, 1u << q, run, segm, cnt, lists);
         }
     }
