@@ -6487,7 +6487,13 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
         int scan_forks = 0;          // side streams that run a scan launch of this call
         // k_scan3 (content identities, 31 paths per tile) takes what k_scan2 took unless
         // GFAL_SCAN=2 asks for the older kernel
-        const bool use3 = n_segs2 > 0 && !children && s->scan_mode != 2;
+        // or the batch is small: k_tile works a tile through in one workgroup, ~0.1 ms whatever
+        // the batch, which a few hundred paths do not pay back (scripts/small_batch_probe.py:
+        // 128 paths 0.12 ms with k_scan2 against 0.24 ms, even at 512, 4096 paths 0.50 against 1.61)
+        int scan3_min_paths = 512;
+        if (const char *env = getenv("GFAL_SCAN3_MIN_PATHS")) scan3_min_paths = atoi(env);
+        const bool use3 = n_segs2 > 0 && !children && s->scan_mode != 2 &&
+                          (n_paths >= scan3_min_paths || s->scan_mode == 3);
         if (use3) {
             const int rc3 = launch_scan3(s, st, items, L, n_paths, max_path_len, filter, n_segs2, item_lo_chain,
                                          want_groups, slots, d_counts, wl_count, d_hist,

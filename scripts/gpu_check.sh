@@ -12,7 +12,8 @@ tail -1 gpurun_out/bench_$tag.log | python -c "
 import sys, json
 d = json.loads(sys.stdin.read())
 r = d['roofline']
-print('paths/s %.0f  ms/step %.2f  scan %.2f ms  dp %.2f ms  call %.2f ms  frac %.3f  tile %d wg %d dp_pairs %d' % (
-    d['value'], d['ms_per_step'], r['kernel_ms'], r['dp_kernel_ms'], r['call_ms'], r['frac'],
+print('paths/s %.0f  ms/step %.2f  k_scan3 %.2f ms  scan phase %.2f ms  dp %.2f ms  call %.2f ms  frac %s  tile %d wg %d dp_pairs %d' % (
+    d['value'], d['ms_per_step'], r['kernel_ms'], r['scan_phase_ms'], r['dp_kernel_ms'], r['call_ms'],
+    ('%.3f' % r['frac']) if r['frac'] is not None else 'withheld (counters of another build)',
     d['config']['tile_paths'], d['config']['workgroups'], d['config']['dp_pairs_per_step']))
 "

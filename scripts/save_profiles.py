@@ -1,9 +1,13 @@
 """Condense gpurun_out/prof_<tag>_* (scripts/collect_profiles.sh) into profiles/."""
 import collections, csv, glob, json, os, shutil, sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
-# longest key first: "k_scan2" before "k_scan"
-KEYS = ("k_scan2", "k_scan", "k_dp_regs<4", "k_dp_regs<8", "k_dp_regs<16", "k_dp_regs<32", "k_dp_long",
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+try:
+    build_id = open("gpurun_out/build_id_%s.txt" % tag).read().strip()
+except OSError:
+    build_id = None
+# longest key first: "k_scan3" / "k_scan2" before "k_scan"
+KEYS = ("k_scan3", "k_scan2", "k_scan", "k_tile_masks", "k_tile", "k_overhang", "k_dp_regs<4", "k_dp_regs<8", "k_dp_regs<16", "k_dp_regs<32", "k_dp_long",
         "k_dp_sys", "k_len_sort_block", "k_prep", "k_wl_scatter", "k_wl_offsets", "k_unpermute",
         "read_u16", "read_b128")
 
@@ -48,6 +52,8 @@ pmc = {
                 "coalesced streams (gfx950 rule of MI355X_MICROARCH.md): bytes = FETCH_SIZE*1024*2"},
     "FETCH_SIZE": summ("fetch"), "WRITE_SIZE": summ("write"), "L2": summ("tcc"),
     "SQ_1": summ("sq1"), "SQ_2": summ("sq2"), "GRBM": summ("grbm"),
+    "SQ_1 prologue only (GFAL_DEBUG_SCAN2=1)": summ("sq1p"),
+    "build_id": build_id,
 }
 json.dump(pmc, open("profiles/%s_pmc_config3.json" % tag, "w"), indent=1)
 
@@ -64,7 +70,7 @@ def scan_span():
         k = kernel_key(r["Kernel_Name"])
         if k == "k_prep":
             cur = [None, None, 0]
-        elif k in ("k_scan2", "k_scan") and cur is not None:
+        elif k in ("k_scan3",) and cur is not None:
             s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
             cur[0] = s if cur[0] is None else min(cur[0], s)
             cur[1] = e if cur[1] is None else max(cur[1], e)
@@ -85,17 +91,17 @@ json.dump(span, open("profiles/%s_scan_span.json" % tag, "w"), indent=1)
 print(json.dumps(span, indent=1))
 
 
-def per_step(group, counter):
-    """sum over the scan kernels' dispatches of one bench step"""
+def per_step(group, counter, kernels=("k_scan3",)):
+    """sum over the dispatches of one bench step of the dominant kernel (k_scan3)"""
     tot = 0.0
-    for k in ("k_scan2", "k_scan"):
+    for k in kernels:
         tot += pmc[group].get(k, {}).get(counter, {}).get("per_step", 0.0)
     return tot
 
 
 fetch, write = per_step("FETCH_SIZE", "FETCH_SIZE"), per_step("WRITE_SIZE", "WRITE_SIZE")
 traffic = {
-    "workload": "config3", "kernels": "k_scan2 (one launch per alignment-length group) + k_scan, summed per step",
+    "workload": "config3", "kernels": "k_scan3", "build_id": build_id,
     "FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write,
     "hbm_bytes_per_launch": int(fetch * 1024 * 2 + write * 1024),
     "method": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over bench.py; read side "
@@ -105,8 +111,13 @@ traffic = {
     "source": "profiles/%s_pmc_config3.json" % tag}
 json.dump(traffic, open("profiles/traffic_config3.json", "w"), indent=1)
 issue = {
-    "workload": "config3", "kernels": "k_scan2 (one launch per alignment-length group) + k_scan, summed per step",
+    "workload": "config3", "kernels": "k_scan3", "build_id": build_id,
     "valu_wave_insts_per_step": per_step("SQ_1", "SQ_INSTS_VALU"),
+    "prologue_valu_wave_insts_per_step": per_step("SQ_1 prologue only (GFAL_DEBUG_SCAN2=1)", "SQ_INSTS_VALU"),
+    "useful_valu_wave_insts_per_step": per_step("SQ_1", "SQ_INSTS_VALU") -
+                                       per_step("SQ_1 prologue only (GFAL_DEBUG_SCAN2=1)", "SQ_INSTS_VALU"),
+    "step_kernels_valu_wave_insts": {k: pmc["SQ_1"].get(k, {}).get("SQ_INSTS_VALU", {}).get("per_step")
+                                     for k in ("k_scan3", "k_tile", "k_tile_masks", "k_overhang", "k_scan", "k_prep")},
     "salu_wave_insts_per_step": per_step("SQ_1", "SQ_INSTS_SALU"),
     "lds_wave_insts_per_step": per_step("SQ_1", "SQ_INSTS_LDS"),
     "vmem_rd_wave_insts_per_step": per_step("SQ_1", "SQ_INSTS_VMEM_RD"),
