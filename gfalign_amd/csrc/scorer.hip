@@ -5640,12 +5640,17 @@ static int create_impl(const int32_t *aln_off, const int32_t *aln_steps, int64_t
     // table per tile and length, which pays from a few dozen items up), then the
     // rare ones (k_scan).  The shards of one set agree on the order (same input)
     // and on who takes which group of 64 (below).
-    int hash_min_items = 48;
+    // (k_scan2 built a window table per (tile, length): worth it from ~48 items on.  With
+    // k_tile / k_scan3 a length costs a tile one light workgroup and k_scan -- chain walks for
+    // 6 paths at a time -- costs ~2 us per item at 10 000 paths: from 4 items on a length is a
+    // segment of its own, whatever the number of shards.  The shard that ended up with the rare
+    // lengths of an 8-way split took 0.62 ms for 14 000 alignments before, 0.43 of it in k_scan.)
+    int hash_min_items = 4;
     if (const char *env = getenv("GFAL_HASH_MIN_ITEMS")) hash_min_items = std::max(1, atoi(env));
     std::vector<int> len_order;
     std::vector<char> is_hash_len((size_t)max_len + 1, 0);
     for (int m = 1; m <= max_len; ++m)
-        if ((int64_t)by_len[(size_t)m].size() >= (int64_t)hash_min_items * WAVE * n_shards) {
+        if ((int64_t)by_len[(size_t)m].size() >= (int64_t)hash_min_items * WAVE) {
             is_hash_len[(size_t)m] = 1;
             len_order.push_back(m);
         }

@@ -9,12 +9,17 @@ number of ranks and any partition.
 
 The partition the PRODUCT uses (bench.py, the CLI) is made inside the scorer:
 every rank hands gfal_scorer_create_sharded the whole set, the library sorts it
-the way the kernels want it (length buckets, content order) and keeps every
-n-th group of 64 -- policy "product" here asks the library for exactly that
-assignment (gfal_shard_owner, host code, no GPU needed).  "range" (contiguous
-ranges balanced by step count) and "content" (copies of one alignment kept
-together) are earlier policies kept for comparison: correct, but slower on the
-GPU.
+the way the kernels want it (length buckets, content order) and keeps its share
+of the groups of 64: the alignment lengths are laid on a line in item order (a
+fixed stretch for holding a length at all, then its groups weighted by what one
+costs), rank k owns the k-th n-th of the line, and group i of a length falls on
+its stretch at frac(i * golden ratio) -- so a rank holds FEW lengths (the scan
+pays a fixed cost per length it holds) and its groups are spread over the whole
+content order.  Policy "product" here asks the library
+for exactly that assignment (gfal_shard_owner, host code, no GPU needed).
+"range" (contiguous ranges balanced by step count) and "content" (copies of one
+alignment kept together) are earlier policies kept for comparison: correct, but
+slower on the GPU.
 """
 import numpy as np
 

@@ -1,9 +1,10 @@
 """CPU, world_size 2 over gloo: the multi-GPU contract of SURVEY.md 8(e).
 
 Each rank takes its shard of the alignments -- the partition the PRODUCT makes
-(gfal_scorer_create_sharded keeps every n-th group of 64 of its own sorted
-order; gfal_shard_owner reports that assignment from host code, so it can be
-checked here) -- produces the per-path counters for the whole candidate batch,
+(gfal_scorer_create_sharded keeps its share of the groups of 64 of its own sorted
+order: few alignment lengths per rank, the groups of a length spread over the
+whole content order; gfal_shard_owner reports that assignment from host code, so
+it can be checked here) -- produces the per-path counters for the whole candidate batch,
 and the [3P] integer counters are summed with one all-reduce.  On the GPU box
 the per-rank scorer is the HIP path and the backend is RCCL
 (tests/test_gpu_multi_rank.py runs bench.py's N-rank path there); here the
