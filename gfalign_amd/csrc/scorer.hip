@@ -5675,13 +5675,16 @@ static int create_impl(const int32_t *aln_off, const int32_t *aln_steps, int64_t
     // (what a group costs depends on how many of the batch's paths its alignments can be on: about
     // proportional to the length at config 3, 7 + length at config 5; 3 + length is in between)
     auto group_weight = [](int m) { return (uint64_t)(36 + 12 * m); };
-    uint64_t shard_fixed = 180000;      // (~2000 groups of average length; the k_scan launch of the rare lengths: twice that)
+    // (~270 groups of average length: what a length costs a shard with k_tile / k_scan3 -- one
+    // light workgroup per tile; k_scan2's table per (tile, length) cost ~2000; the k_scan
+    // launch of the rare lengths: twice that)
+    uint64_t shard_fixed = 24000;
     if (const char *env = getenv("GFAL_SHARD_FIXED")) shard_fixed = (uint64_t)std::max(0ll, atoll(env));
     std::vector<uint64_t> len_w_lo((size_t)max_len + 2, 0);      // where a length's groups start on the line
     uint64_t total_w = 0;
     {
         // (a small set: the fixed stretches must not crowd the groups off the line, or
-        // shards end up empty -- at most twice the groups' share per length)
+        // shards end up empty -- at most a quarter of the groups' share per length)
         uint64_t items_w = 0, n_charged = 0;
         bool any_rare = false;
         for (int m : len_order) {
@@ -5690,7 +5693,7 @@ static int create_impl(const int32_t *aln_off, const int32_t *aln_steps, int64_t
             else any_rare = true;
         }
         n_charged += any_rare ? 2 : 0;
-        if (n_charged) shard_fixed = std::min(shard_fixed, 2 * items_w / n_charged + 1);
+        if (n_charged) shard_fixed = std::min(shard_fixed, items_w / (4 * n_charged) + 1);
         bool rare_seen = false;
         for (int m : len_order) {
             if (is_hash_len[(size_t)m]) total_w += shard_fixed;

@@ -84,14 +84,13 @@ def test_product_partition_is_what_the_library_reports():
         owner = shard.product_owner(t.aln_off, t.aln_steps, t.V, world)
         assert owner.min() >= 0 and owner.max() == world - 1
         steps = np.bincount(owner, weights=np.diff(t.aln_off).astype(np.float64), minlength=world)
-        # A shard holds few alignment lengths (each costs it a prologue per tile whatever it
+        # A shard holds few alignment lengths (each costs it a workgroup per tile whatever it
         # holds of it) and the groups of a length are spread over its shards: what balances
-        # is groups + a fixed charge per length, not the step count -- within 25 % at 2 and 3
-        # shards of this small set; 8 shards of 100 k alignments are more shards than
-        # lengths worth holding (some stay empty: the counters still add up).
+        # is groups weighted by what one costs + a small charge per length, not the step
+        # count -- within a third at 2 and 3 shards of this small set.
         assert steps.sum() == t.S
         if world <= 3:
-            assert steps.max() - steps.min() < 0.25 * t.S / world
+            assert steps.max() - steps.min() < 0.33 * t.S / world
         assert np.array_equal(owner, shard.product_owner(t.aln_off, t.aln_steps, t.V, world))
     off = np.array([0, 0, 2, 2, 5], np.int32)         # two zero-step alignments
     st = np.array([0, 2, 4, 2, 0], np.int32)
