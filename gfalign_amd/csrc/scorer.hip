@@ -5126,6 +5126,7 @@ struct gfal_scorer {
     // kept in a ring and averaged by gfal_scorer_get_info
     static constexpr int EV_RING = 128;
     bool profiling = false;
+    bool prof_all = true;                // false: only the dominant scan kernel is bracketed (enable == 2)
     hipEvent_t ev[EV_RING][6] = {};      // [4], [5]: around the dominant scan kernel (k_scan3)
     bool ev_scan3 = false;               // the last profiled call recorded them
     int ev_calls = 0;   // calls recorded since profiling was switched on
@@ -6061,6 +6062,7 @@ int gfal_scorer_set_profiling(gfal_scorer *s, int enable)
                 if (!e) HIP_TRY(hipEventCreate(&e));
     }
     s->profiling = enable != 0;
+    s->prof_all = enable != 2;
     s->ev_calls = 0;
     return GFAL_OK;
 }
@@ -6383,7 +6385,7 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
     }
     hipEvent_t *ev = s->ev[s->ev_calls % gfal_scorer::EV_RING];
     if (s->profiling) {
-        HIP_TRY(hipEventRecord(ev[0], st));
+        if (s->prof_all) HIP_TRY(hipEventRecord(ev[0], st));
         s->ev_scan3 = false;
     }
 
@@ -6425,7 +6427,7 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
                        s->d_node_hist, (uint32_t)s->n_steps, s->n_empty, filter, L,
                        d_order, s->d_images, d_counts, s->d_status, d_hist, s->d_lids, pc);
     HIP_TRY(hipGetLastError());
-    if (s->profiling) HIP_TRY(hipEventRecord(ev[1], st));
+    if (s->profiling && s->prof_all) HIP_TRY(hipEventRecord(ev[1], st));
 
     s->last_tile = 0;
     s->last_grid = 0;
@@ -6659,7 +6661,7 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
         if (cx && cx->mode == 1)      // good-without-DP, before the DP kernels add theirs
             hipLaunchKernelGGL(k_store_snapshot, dim3(p_blocks), dim3(256), 0, st, d_counts, (int)n_paths,
                                cx->d_g1_tmp);
-        if (s->profiling) HIP_TRY(hipEventRecord(ev[2], st));
+        if (s->profiling && s->prof_all) HIP_TRY(hipEventRecord(ev[2], st));
 
         // a search's batches: a short list last time (and no alignment longer than a wave)
         // -> one launch runs every DP class, on the list as it was pushed
@@ -6704,18 +6706,24 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
         // every kernel of both families is launched; the list length (known on
         // the device only) decides which family returns at once
         if (!dp_small) {
+        const bool big = n_paths >= 2048;
         hipLaunchKernelGGL(k_dp_sys<4>, dim3(DP_SYS_BLOCKS), dim3(DP_THREADS), 0, st, d);
         hipLaunchKernelGGL((k_dp_regs<4, 0>), dim3(DP_REG_BLOCKS), dim3(DP_THREADS), 0, st, d);
         if (s->max_aln_len > 4) {
             hipStream_t s0 = side(0);
+            // (a big batch: the throughput kernel first -- behind the other family's launch,
+            // whose workgroups return at once but queue for CU slots behind k_dp_regs<4>'s, it
+            // started 110 us late at config 3)
+            if (big) hipLaunchKernelGGL((k_dp_regs<8, 1>), dim3(DP_REG_BLOCKS), dim3(DP_THREADS), 0, s0, d);
             hipLaunchKernelGGL(k_dp_sys<8>, dim3(DP_SYS_BLOCKS), dim3(DP_THREADS), 0, s0, d);
-            hipLaunchKernelGGL((k_dp_regs<8, 1>), dim3(DP_REG_BLOCKS), dim3(DP_THREADS), 0, s0, d);
+            if (!big) hipLaunchKernelGGL((k_dp_regs<8, 1>), dim3(DP_REG_BLOCKS), dim3(DP_THREADS), 0, s0, d);
         }
         if (s->max_aln_len > 8) {
             hipStream_t s1 = side(1);
             // up to 32 k entries, two per wave: enough blocks that none loops for long
+            if (big) hipLaunchKernelGGL((k_dp_regs<16, 2>), dim3(DP_REG_BLOCKS), dim3(DP_THREADS), 0, s1, d);
             hipLaunchKernelGGL(k_dp_sys<16>, dim3(4 * DP_SYS_BLOCKS), dim3(DP_THREADS), 0, s1, d);
-            hipLaunchKernelGGL((k_dp_regs<16, 2>), dim3(DP_REG_BLOCKS), dim3(DP_THREADS), 0, s1, d);
+            if (!big) hipLaunchKernelGGL((k_dp_regs<16, 2>), dim3(DP_REG_BLOCKS), dim3(DP_THREADS), 0, s1, d);
         }
         if (s->max_aln_len > 16) {
             hipStream_t s2 = side(2);
@@ -6742,7 +6750,7 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
         if (cx && cx->mode == 1)
             hipLaunchKernelGGL(k_store_snapshot, dim3(p_blocks), dim3(256), 0, st, d_counts, (int)n_paths,
                                cx->d_g1_tmp);
-        if (s->profiling) HIP_TRY(hipEventRecord(ev[2], st));
+        if (s->profiling && s->prof_all) HIP_TRY(hipEventRecord(ev[2], st));
     }
     if (cx && cx->mode == 1)
         hipLaunchKernelGGL(k_store_paths, dim3((unsigned)n_paths), dim3(256), 0, st, d_path_off, d_path_steps,
@@ -6756,7 +6764,7 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
                            (int)n_paths, d_user_counts, s->d_status, status_copy);
     HIP_TRY(hipGetLastError());
     if (s->profiling) {
-        HIP_TRY(hipEventRecord(ev[3], st));
+        if (s->prof_all) HIP_TRY(hipEventRecord(ev[3], st));
         ++s->ev_calls;
     }
     s->last_stream = st;
@@ -7737,11 +7745,13 @@ int gfal_scorer_get_info(gfal_scorer *s, gfal_info *out)
             for (int i = 0; i < n; ++i) {
                 hipEvent_t *ev = s->ev[i];
                 float t = 0.f;
-                HIP_TRY(hipEventSynchronize(ev[3]));
                 if (s->ev_scan3) {
+                    HIP_TRY(hipEventSynchronize(ev[5]));
                     HIP_TRY(hipEventElapsedTime(&t, ev[4], ev[5]));
                     scan3 += t;
                 }
+                if (!s->prof_all) continue;
+                HIP_TRY(hipEventSynchronize(ev[3]));
                 HIP_TRY(hipEventElapsedTime(&t, ev[1], ev[2]));
                 scan += t;
                 HIP_TRY(hipEventElapsedTime(&t, ev[2], ev[3]));

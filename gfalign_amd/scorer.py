@@ -241,7 +241,9 @@ class Scorer:
         return fw, rc
 
     def set_profiling(self, on=True):
-        _check(self._lib.gfal_scorer_set_profiling(self._h, int(bool(on))))
+        """True / 1: events around every phase of a call; 2: around the dominant scan
+        kernel only (what bench.py's timed region uses); False: none."""
+        _check(self._lib.gfal_scorer_set_profiling(self._h, 2 if on == 2 else int(bool(on))))
 
     def info(self):
         out = GfalInfo()

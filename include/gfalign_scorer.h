@@ -296,7 +296,10 @@ typedef struct {
 } gfal_info;
 
 /* Record HIP events (on the caller's stream) around the kernels of each score
-   call; switching it on resets the statistics.  Off by default. */
+   call; switching it on resets the statistics.  Off by default.  enable == 1:
+   every phase (scan_ms, scan_kernel_ms, dp_ms, total_ms; the events cost a
+   10 000-path step about 3 %); enable == 2: the dominant scan kernel only
+   (scan_kernel_ms; the other times stay 0). */
 int gfal_scorer_set_profiling(gfal_scorer *s, int enable);
 /* Blocks on the recorded events when profiling is on. */
 int gfal_scorer_get_info(gfal_scorer *s, gfal_info *out);
