@@ -7451,6 +7451,113 @@ static int group_children_impl(gfal_group *g, int32_t n, const int32_t *parent, 
     return rc;
 }
 
+// The counters of the batch that just finished on every shard (P paths), summed
+// over the shards unless the devices already did that.
+static void group_gather(gfal_group *g, int32_t P, uint32_t *bad, uint32_t *good, uint32_t *unaligned)
+{
+    const size_t D = g->shards.size();
+    const size_t n_cnt = (size_t)3 * P;
+    const uint32_t *h = g->shards[0]->h_out;
+    if (g->comms.empty() && D > 1) {
+        g->h_sum.assign(n_cnt, 0u);
+        for (size_t d = 0; d < D; ++d)
+            for (size_t k = 0; k < n_cnt; ++k) g->h_sum[k] += g->shards[d]->h_out[k];
+        h = g->h_sum.data();
+    }
+    memcpy(bad, h, (size_t)P * sizeof(uint32_t));
+    memcpy(good, h + P, (size_t)P * sizeof(uint32_t));
+    if (unaligned) memcpy(unaligned, h + 2 * (size_t)P, (size_t)P * sizeof(uint32_t));
+}
+
+// May the lists grow to `need` pairs, or must the batch be split?  (GFAL_DEBUG_WL_NO_GROW
+// forces the split path in tests.)
+static bool worklist_may_grow(unsigned long long need)
+{
+    return need + need / 4 + 1024 <= WL_MAX_ENTRIES && getenv("GFAL_DEBUG_WL_NO_GROW") == nullptr;
+}
+
+// Paths [lo, hi) of a batch whose exact-DP need is beyond what the lists may grow to,
+// run on their own (blocking), halved again while they still overflow -- what
+// score_range does for the one-scorer call.  `in` is a host copy of the whole batch in
+// the staging layout: [offsets | steps | slots], or [parent | step | slot] of a children
+// batch (parents precede their children in one, so the halves are run in order: the first
+// half is in the store when the second names it -- by slot, see below).
+static int group_run_range(gfal_group *g, const std::vector<int32_t> &in, int32_t P0, int32_t lo, int32_t hi,
+                           uint32_t *bad, uint32_t *good, uint32_t *unaligned)
+{
+    const int32_t P = hi - lo;
+    const size_t D = g->shards.size();
+    g->pend_paths = P;
+    int rc;
+    std::vector<int32_t> off;
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        if (g->pend_kind == 2) {
+            // a parent inside the batch is named by its index there: by its index in this
+            // piece, or -- scored by an earlier piece -- by the slot it was kept in
+            const int32_t *slot = in.data() + 2 * (size_t)P0;
+            off.resize((size_t)P);
+            for (int32_t k = 0; k < P; ++k) {
+                int32_t par = in[(size_t)(lo + k)];
+                if (par < 0) {
+                    const int32_t j = ~par;
+                    if (j >= lo)
+                        par = ~(j - lo);
+                    else if (j >= 0 && slot[j] >= 0)
+                        par = slot[j];
+                    else {
+                        set_err("exact-DP worklist: the children batch cannot be split (a parent inside it is not kept)");
+                        return GFAL_E_NOMEM;
+                    }
+                }
+                off[(size_t)k] = par;
+            }
+            rc = group_enqueue(g, off.data(), in.data() + P0 + lo, slot + lo);
+        } else {
+            off.resize((size_t)P + 1);
+            for (int32_t p = 0; p <= P; ++p) off[(size_t)p] = in[(size_t)(lo + p)] - in[(size_t)lo];
+            const int32_t *steps = in.data() + P0 + 1;
+            rc = group_enqueue(g, off.data(), steps + in[(size_t)lo], steps + in[(size_t)P0] + lo);
+        }
+        if (rc) return rc;
+        bool again = false, split = false;
+        for (size_t d = 0; d < D; ++d) {
+            gfal_scorer *s = g->shards[d];
+            HIP_TRY(hipSetDevice(s->device));
+            HIP_TRY(hipStreamSynchronize(s->stream));
+            const uint32_t *st4 = s->h_out + (size_t)3 * P;
+            memcpy(s->cached_status, st4, 4 * sizeof(uint32_t));
+            s->status_cached = true;
+            rc = status_to_code(s, st4);
+            if (rc == GFAL_E_NOMEM) {
+                const unsigned long long need = (unsigned long long)st4[2] | ((unsigned long long)st4[3] << 32);
+                ++s->n_overflow_reruns;
+                if (!worklist_may_grow(need))
+                    split = true;
+                else if ((rc = grow_worklist(s, need)))
+                    return rc;
+                again = true;
+            } else if (rc) {
+                return rc;
+            }
+        }
+        if (!again) {
+            group_gather(g, P, bad + lo, good + lo, unaligned ? unaligned + lo : nullptr);
+            return GFAL_OK;
+        }
+        if (split) {
+            if (P == 1) {
+                set_err("exact-DP worklist: one path needs more pairs than the lists may hold");
+                return GFAL_E_NOMEM;
+            }
+            const int32_t mid = lo + P / 2;
+            if ((rc = group_run_range(g, in, P0, lo, mid, bad, good, unaligned))) return rc;
+            return group_run_range(g, in, P0, mid, hi, bad, good, unaligned);
+        }
+    }
+    set_err("exact-DP worklist kept overflowing");
+    return GFAL_E_NOMEM;
+}
+
 static int group_end_impl(gfal_group *g, uint32_t *bad, uint32_t *good, uint32_t *unaligned)
 {
     if (!g->pending) {
@@ -7462,7 +7569,7 @@ static int group_end_impl(gfal_group *g, uint32_t *bad, uint32_t *good, uint32_t
     const int32_t P = g->pend_paths;
     const size_t n_cnt = (size_t)3 * P;
     for (int attempt = 0; attempt < 4; ++attempt) {
-        bool again = false;
+        bool again = false, split = false;
         for (size_t d = 0; d < D; ++d) {
             gfal_scorer *s = g->shards[d];
             HIP_TRY(hipSetDevice(s->device));
@@ -7474,33 +7581,41 @@ static int group_end_impl(gfal_group *g, uint32_t *bad, uint32_t *good, uint32_t
             if (rc == GFAL_E_NOMEM) {        // worklist overflow on this shard: grow, run the batch again
                 const unsigned long long need = (unsigned long long)st4[2] | ((unsigned long long)st4[3] << 32);
                 ++s->n_overflow_reruns;
-                const int grown = grow_worklist(s, need);
-                if (grown) return grown;
+                if (!worklist_may_grow(need)) {
+                    split = true;
+                } else {
+                    const int grown = grow_worklist(s, need);
+                    if (grown) return grown;
+                }
                 again = true;
             } else if (rc) {
                 return rc;
             }
         }
         if (!again) {
-            if (!g->comms.empty() || D == 1) {
-                const uint32_t *h = g->shards[0]->h_out;
-                memcpy(bad, h, (size_t)P * sizeof(uint32_t));
-                memcpy(good, h + P, (size_t)P * sizeof(uint32_t));
-                if (unaligned) memcpy(unaligned, h + 2 * (size_t)P, (size_t)P * sizeof(uint32_t));
-            } else {
-                g->h_sum.assign(n_cnt, 0u);
-                for (size_t d = 0; d < D; ++d)
-                    for (size_t k = 0; k < n_cnt; ++k) g->h_sum[k] += g->shards[d]->h_out[k];
-                memcpy(bad, g->h_sum.data(), (size_t)P * sizeof(uint32_t));
-                memcpy(good, g->h_sum.data() + P, (size_t)P * sizeof(uint32_t));
-                if (unaligned) memcpy(unaligned, g->h_sum.data() + 2 * (size_t)P, (size_t)P * sizeof(uint32_t));
-            }
+            group_gather(g, P, bad, good, unaligned);
             return GFAL_OK;
         }
         // the batch is still in shard 0's pinned staging buffer: [offsets | steps | slots],
         // or [parent | step | slot] of a children batch (re-running one is idempotent:
         // the store receives the same paths and counters again)
         const int32_t *h_in = g->shards[0]->h_in;
+        if (split) {
+            // more pairs than the lists may ever hold: the batch in halves (the sub-batches
+            // reuse the staging buffer, so the batch is copied out of it first)
+            if (P == 1) {
+                set_err("exact-DP worklist: one path needs more pairs than the lists may hold");
+                return GFAL_E_NOMEM;
+            }
+            const size_t n_in = g->pend_kind == 2 ? (size_t)3 * P
+                                                  : (size_t)P + 1 + (size_t)h_in[P] + (g->pend_kind == 1 ? (size_t)P : 0);
+            const std::vector<int32_t> in(h_in, h_in + n_in);
+            const int32_t mid = P / 2;
+            int rc = group_run_range(g, in, P, 0, mid, bad, good, unaligned);
+            if (!rc) rc = group_run_range(g, in, P, mid, P, bad, good, unaligned);
+            g->pend_paths = P;
+            return rc;
+        }
         const int rc = g->pend_kind == 2 ? group_enqueue(g, h_in, h_in + P, h_in + 2 * (size_t)P)
                                          : group_enqueue(g, h_in, h_in + P + 1, h_in + P + 1 + h_in[P]);
         if (rc) return rc;

@@ -401,7 +401,12 @@ public:
         if (incr_) {
             min_parent_ = (size_t)std::max<int32_t>(1, scorer_.max_aln_len());
             store_cap_ = 1 << 14;
-            if (!scorer_.store_reserve(store_cap_)) return EXIT_FAILURE;
+            if (!scorer_.store_reserve(store_cap_)) {
+                // (no room for the device-side path store: every candidate is scored in full
+                // instead -- same rows, more work)
+                fprintf(stderr, "gfalign: no device memory for the path store, candidates are scored in full\n");
+                incr_ = false;
+            }
         }
 
         auto first = std::make_unique<Node>();

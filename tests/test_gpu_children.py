@@ -176,6 +176,55 @@ def test_first_node_list_longer_than_the_bitmaps(gpu, monkeypatch):
             frontier = [(slot[k], full[k]) for k in range(0, len(full), 3)][:5]
 
 
+@pytest.mark.parametrize("n_shards", [1, 2])
+def test_a_batch_beyond_the_worklist_limit_is_split(gpu, monkeypatch, n_shards):
+    """GFAL_DEBUG_WL_NO_GROW stands for a batch whose exact-DP need is beyond what the lists
+    may grow to: gfal_group_score_end runs it in halves (plain, stored and children batches;
+    a parent inside a children batch is named by its slot once an earlier piece scored it)."""
+    monkeypatch.setenv("GFAL_DEBUG_WL_CAPACITY", "1")       # = one entry per alignment
+    monkeypatch.setenv("GFAL_DEBUG_WL_NO_GROW", "1")
+    rnd = random.Random(5)
+    n_nodes, max_m = 3, 7
+    walk = [(rnd.randrange(n_nodes) << 1) | rnd.randrange(2) for _ in range(100)]
+    alns = walk_alignments(rnd, walk, n_nodes, 3000, max_m, mutate=0.5)
+    aoff, ast = csr(alns)
+    scs = [Scorer(aoff, ast, n_nodes + 2, shard=(k, n_shards)) for k in range(n_shards)]
+    try:
+        with Group(scs) as g:
+            roots = [walk[s:s + max_m + 3] for s in range(0, 40, 3)]
+            poff, pst = csr(roots)
+            res = g.evaluate_paths(poff, pst, True)
+            assert_same(res, expect(alns, roots), "plain batch")
+            assert sum(sc.info()["n_overflow_reruns"] for sc in scs) >= 1
+            tree = Tree(g, 400)
+            slots, res = tree.store(roots)
+            assert_same(res, expect(alns, roots), "stored batch")
+            batch = []
+            for s, p in zip(slots, roots):
+                for st in {walk[(walk.index(p[-1]) + 1) % len(walk)], p[-1] ^ 1, p[0]}:
+                    batch.append((("slot", s), st))
+            # a chain of children inside the batch, its links spread over it (they cross the halves)
+            base, batch, links = batch, [], []
+            every = max(2, len(base) // 6)
+            for k, entry in enumerate(base):
+                batch.append(entry)
+                if k % every == every - 1:
+                    batch.append((("batch", links[-1] if links else 1), walk[(7 * k) % len(walk)]))
+                    links.append(len(batch) - 1)
+            assert len(links) >= 4
+            before = sum(sc.info()["n_overflow_reruns"] for sc in scs)
+            slot, full, res = tree.children(batch)
+            assert_same(res, expect(alns, full), "children batch")
+            assert sum(sc.info()["n_overflow_reruns"] for sc in scs) > before
+            # the pieces kept their paths: a later batch may name them
+            batch2 = [(("slot", slot[k]), walk[k % len(walk)]) for k in links]
+            _, full2, res2 = tree.children(batch2, keep=False)
+            assert_same(res2, expect(alns, full2), "grandchildren")
+    finally:
+        for sc in scs:
+            sc.close()
+
+
 @pytest.mark.parametrize("dedup", [False, True])
 def test_shards_and_dedup(gpu, dedup):
     """Two shards of one set on one device (counters added on the host) and the
