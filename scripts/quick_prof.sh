@@ -5,7 +5,7 @@
 # gpurun_out/qp_<tag>_*.
 tag=${1:-x}; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
-B="python3 bench.py --no-cpu-baseline $*"
+B="python3 bench.py --no-cpu-baseline --no-search-mode $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/qp_${tag}_stats -- $B --steps 10 --warmup 2 > gpurun_out/qp_${tag}_stats.log 2>&1
 python3 scripts/kstats.py gpurun_out/qp_${tag}_stats
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_BRANCH --output-format csv -d gpurun_out/qp_${tag}_sq1 -- $B --steps 2 --warmup 1 > /dev/null 2>&1

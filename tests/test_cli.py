@@ -224,7 +224,7 @@ def test_eval_path_appendix_c2(cli, gpu):
     assert out.splitlines() == gold["stdout"]
     rc, out, err = run(cli, ["evalPath", "-f", REF_FILES + "/random3.gfa", "-g",
                              REF_FILES + "/random3.gaf", "-p", gold["path"]],
-                       env={"GFALIGN_DEDUP": "1"})
+                       env={"GFALIGN_DEDUP": "0"})      # (one lane per alignment; the default collapses identical ones)
     assert rc == 0, err
     assert out.splitlines() == gold["stdout"]
 
@@ -263,9 +263,10 @@ def test_search_on_a_synthetic_tangle_matches_oracle(cli, gpu, tmp_path):
     rc, out, err = run(cli, base + ["--devices", "3"], env={"GFALIGN_SHARE_DEVICE": "1"})
     assert rc == 0, err
     assert out == outs[0]
-    # identical alignments collapsed into weighted lanes, sharded or not: same bytes
+    # one lane per alignment instead of identical alignments collapsed into weighted lanes
+    # (the default), sharded or not: same bytes
     for extra in ([], ["--devices", "2"]):
-        rc, out, err = run(cli, base + extra, env={"GFALIGN_SHARE_DEVICE": "1", "GFALIGN_DEDUP": "1"})
+        rc, out, err = run(cli, base + extra, env={"GFALIGN_SHARE_DEVICE": "1", "GFALIGN_DEDUP": "0"})
         assert rc == 0, err
         assert out == outs[0]
     assert outs[0].splitlines() == exp
