@@ -2229,25 +2229,42 @@ __device__ __forceinline__ uint32_t *dp_row(uint32_t *row_scratch, int &stride)
 // STEP_INVALID; columns beyond the lane's own m are computed and ignored
 // (nothing flows from a column to its left).  Column 0 is never written by
 // the reference: it is 0 in every row.
+//
+// A cell is ONE word: dp * 2^14 + (-x), x = the exit value that travels with the
+// traceback (0 .. -MC: it is set in row 0 / column 0 only, src/alignments.cpp:500),
+// bits 13..12 free.  The three candidates get their rank in the reference's tie order
+// in those two bits -- diagonal 3 (:527, `v == d` first), up 2 and left 1 in the columns
+// before the last (:534, `up >= left`), up 0 in the lane's last column (there up is free
+// and the same test reads `u > l`) -- so one signed max3 picks the value AND carries the
+// winner's exit value: 7 VALU per cell (compare, select, three adds, max3, and) against
+// 12 with dp and x in separate registers (two compares and two selects for x alone).
+constexpr int DPK_SHIFT = 14;
+constexpr int DPK_ONE = 1 << DPK_SHIFT;
+constexpr int DPK_RANK = 1 << 12;
+constexpr int DPK_X_MASK = DPK_RANK - 1;
+
+__device__ __forceinline__ int dpk_pack(int dp, int x) { return dp * DPK_ONE - x; }
+__device__ __forceinline__ int dpk_dp(int c) { return c >> DPK_SHIFT; }
+__device__ __forceinline__ int dpk_x(int c) { return -(c & DPK_X_MASK); }
+
+// what the `up` candidate adds in column j (1-based) of a lane whose alignment has m steps
+__device__ __forceinline__ int dpk_up_add(int j, int m) { return j < m ? 2 * DPK_RANK - DPK_ONE : 0; }
+
 template <int MC>
-__device__ __forceinline__ void dp_row_regs(uint32_t ai, const uint32_t (&b)[MC], int m,
-                                            int (&dp)[MC + 1], int (&x)[MC + 1])
+__device__ __forceinline__ void dp_row_regs(uint32_t ai, const uint32_t (&b)[MC], const int (&up_add)[MC],
+                                            int (&c)[MC + 1])
 {
-    int diag_dp = 0, diag_x = 0, left_dp = 0, left_x = 0;
+    int diag = 0, left = 0;            // column 0: dp 0, exit value 0
 #pragma unroll
     for (int j = 1; j <= MC; ++j) {
-        const int up_dp = dp[j], up_x = x[j];
-        const int d = diag_dp + ((ai == b[j - 1]) ? 0 : -1);
-        const int u = up_dp + ((j < m) ? -1 : 0);
-        const int l = left_dp - 1;
-        const int v = max(d, max(u, l));
-        const int xx = (v == d) ? diag_x : ((up_dp >= left_dp) ? up_x : left_x);
-        dp[j] = v;
-        x[j] = xx;
-        diag_dp = up_dp;
-        diag_x = up_x;
-        left_dp = v;
-        left_x = xx;
+        const int up = c[j];
+        const int d = diag + ((ai == b[j - 1]) ? 3 * DPK_RANK : 3 * DPK_RANK - DPK_ONE);
+        const int u = up + up_add[j - 1];
+        const int l = left + (DPK_RANK - DPK_ONE);
+        const int v = max(d, max(u, l)) & ~(3 * DPK_RANK);
+        c[j] = v;
+        diag = up;
+        left = v;
     }
 }
 
@@ -2322,12 +2339,17 @@ __device__ __forceinline__ int traceback_score_skip(const uint16_t *__restrict__
                                                     const uint32_t (&b)[MC], int m,
                                                     uint32_t (*rowbits)[DP_THREADS], int lane)
 {
-    int dp[MC + 1], x[MC + 1];
+    int c[MC + 1], up_add[MC];
 #pragma unroll
     for (int j = 0; j <= MC; ++j) {
-        dp[j] = (j <= n) ? -j : 0;       // :500, row 0 reaches column n only
-        x[j] = dp[j];
+        const int dp0 = (j <= n) ? -j : 0;       // :500, row 0 reaches column n only
+        c[j] = dpk_pack(dp0, dp0);
     }
+#pragma unroll
+    for (int j = 1; j <= MC; ++j) up_add[j - 1] = dpk_up_add(j, m);
+    typedef __attribute__((address_space(3))) const uint16_t lds_cu16;
+    lds_cu16 *lds_path = (lds_cu16 *)path_lds;
+    const bool any_unstaged = WAVE_ANY(!staged && n > 0);
     int block = -1;                      // current 32-row block of the path
     uint32_t todo = 0;                   // its rows still to compute
     unsigned long long carry = (1ull << m) - 1ull;    // rows 1..m: the state is not steady yet
@@ -2348,13 +2370,16 @@ __device__ __forceinline__ int traceback_score_skip(const uint16_t *__restrict__
         if (todo != 0) {
             const int pos = block * 32 + __builtin_ctz(todo);
             todo &= todo - 1u;
-            const uint32_t ai = staged ? (uint32_t)path_lds[pos] : (uint32_t)astep[pos];
-            dp_row_regs<MC>(ai, b, m, dp, x);
+            // (an LDS read, and an HBM read for the few lanes beyond the staged paths: one
+            // load of a generic pointer would be a flat instruction for every lane)
+            uint32_t ai = lds_path[staged ? pos : 0];
+            if (any_unstaged && !staged) ai = astep[pos];
+            dp_row_regs<MC>(ai, b, up_add, c);
         }
     }
     int r = 0;
 #pragma unroll
-    for (int j = 1; j <= MC; ++j) r = (j == m) ? dp[j] - x[j] : r;
+    for (int j = 1; j <= MC; ++j) r = (j == m) ? dpk_dp(c[j]) - dpk_x(c[j]) : r;
     return r;
 }
 
