@@ -2723,23 +2723,20 @@ __device__ __forceinline__ int from_left_column(int v, bool first_column)
 // whatever the dependencies: running both orientations in one lane doubled the
 // step time, so they go to different lane groups instead.)
 template <int MC>
-__device__ __forceinline__ void sys_step(int s, int j, int n, uint32_t b, int up_cost,
-                                         const uint16_t *arow, uint32_t &a_next, int &l_dp,
-                                         int &l_x, int d_dp, int d_x, int &r_dp, int &r_x)
+__device__ __forceinline__ void sys_step(int s, int j, int n, uint32_t b, int up_add,
+                                         const uint16_t *arow, uint32_t &a_next, int &l, int d, int &r)
 {
-    r_dp = from_left_column<MC>(l_dp, j == 1);
-    r_x = from_left_column<MC>(l_x, j == 1);
+    // cells are the packed words of dp_row_regs: one shift from the left lane, one max3
+    r = from_left_column<MC>(l, j == 1);
     const uint32_t ai = a_next;
     a_next = arow[s + 1];
     // selects, not a branch: the exec-mask round trip through the scalar unit
     // costs a lone wave more than the two extra instructions
     const bool active = (unsigned)(s - j) < (unsigned)n;     // row i = s - c is in 1..n
-    const int d = d_dp + ((ai == b) ? 0 : -1);
-    const int u = l_dp + up_cost;
-    const int v = max(d, max(u, r_dp - 1));
-    const int xx = (v == d) ? d_x : ((l_dp >= r_dp) ? l_x : r_x);   // :527, 534, 541
-    l_x = active ? xx : l_x;
-    l_dp = active ? v : l_dp;
+    const int dd = d + ((ai == b) ? 3 * DPK_RANK : 3 * DPK_RANK - DPK_ONE);      // :527
+    const int u = l + up_add;                                                    // :534 (:504 free in the last column)
+    const int v = max(dd, max(u, r + (DPK_RANK - DPK_ONE))) & ~(3 * DPK_RANK);   // :541
+    l = active ? v : l;
 }
 
 // LDS of one workgroup of the wavefront DP
@@ -2897,10 +2894,10 @@ __device__ __forceinline__ void dp_sys_body(const DpArgs &a, uint32_t block, uin
             uint32_t b = STEP_INVALID;
             if (run && c < m)
                 b = flip ? ((uint32_t)e.bp[(m - 1 - c) * WAVE] ^ 1u) : (uint32_t)e.bp[c * WAVE];
-            const int up_cost = (j < m) ? -1 : 0;         // :504 free in the last column
+            const int up_add = dpk_up_add(j, m);          // :504 free in the last column
             // row 0 of my column (:500; m <= n here, so every column is inside)
-            int l_dp = -j, l_x = -j;                      // my latest cell (i - 1, j)
-            int g_dp = 0, g_x = 0;                        // the diagonal one (i - 1, j - 1)
+            int l = dpk_pack(-j, -j);                     // my latest cell (i - 1, j)
+            int g = 0;                                    // the diagonal one (i - 1, j - 1): dp 0, exit value 0
             int n_max = n;
 #pragma unroll
             for (int o = MC; o < WAVE; o <<= 1) n_max = max(n_max, __shfl_xor(n_max, o, WAVE));
@@ -2910,12 +2907,12 @@ __device__ __forceinline__ void dp_sys_body(const DpArgs &a, uint32_t block, uin
             // path step of the next row is loaded one step ahead
             uint32_t a_next = arow[1];
             for (int s = 1; s < n_max + MC; s += 2) {
-                int h_dp, h_x;
-                sys_step<MC>(s, j, n, b, up_cost, arow, a_next, l_dp, l_x, g_dp, g_x, h_dp, h_x);
-                sys_step<MC>(s + 1, j, n, b, up_cost, arow, a_next, l_dp, l_x, h_dp, h_x, g_dp, g_x);
+                int h;
+                sys_step<MC>(s, j, n, b, up_add, arow, a_next, l, g, h);
+                sys_step<MC>(s + 1, j, n, b, up_add, arow, a_next, l, h, g);
             }
             // lane m-1 of the group holds cell (n, m)
-            good |= run && n > 0 && c == m - 1 && l_dp == l_x;
+            good |= run && n > 0 && c == m - 1 && dpk_dp(l) == dpk_x(l);
         }
         // the entry's lanes: both of its groups
         constexpr int SPAN = MC == 64 ? 64 : 2 * MC;
