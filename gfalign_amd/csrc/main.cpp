@@ -710,6 +710,7 @@ int main(int argc, char **argv)
         if (const char *k = getenv("GFALIGN_INCREMENTAL")) so.incremental = atoi(k) != 0;
         const double t_open = gfal::now_s();
         Search search(g, scorer, so, std::cout);
+        search.set_alignments(packed);      // (GFALIGN_SPEC_POLICY=best: which extensions the speculation follows first)
         int rc = search.run();
         if (verbose_flag)
             fprintf(stderr,

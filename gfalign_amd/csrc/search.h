@@ -368,6 +368,55 @@ public:
         : g_(g), scorer_(scorer), opt_(opt), out_(out)
     {
         if (const char *f = getenv("GFALIGN_DUMP_BATCHES")) dump_ = fopen(f, "wb");
+        if (const char *k = getenv("GFALIGN_SPEC_POLICY")) best_first_ = std::string(k) == "best";
+        if (const char *k = getenv("GFALIGN_SPEC_MIN_LIKE")) min_like_ = (float)atof(k);
+        if (const char *k = getenv("GFALIGN_SPEC_DEPTH")) max_depth_ = std::max(1, std::min(62, atoi(k)));
+    }
+    // Which extensions the speculation follows first (collect_best): an edge that many
+    // alignments take is the likelier continuation.  Counted over (a sample of) the
+    // alignments' consecutive steps, both strands; has no influence on the output.
+    void set_alignments(const PackedAlignments &a)
+    {
+        if (!best_first_) return;
+        const size_t V = g_.adjacency.size();
+        edge_w_.assign(V, {});
+        size_t n_edges = 0;
+        for (size_t u = 0; u < V; ++u) {
+            edge_w_[u].assign(g_.adjacency[u].size(), 0u);
+            n_edges += g_.adjacency[u].size();
+        }
+        if (n_edges == 0 || a.size() == 0) return;
+        // (from step, to step) -> edge, open addressing
+        size_t cap = 16;
+        while (cap < 2 * n_edges) cap <<= 1;
+        std::vector<uint64_t> keys(cap, ~0ull);
+        std::vector<uint32_t *> vals(cap, nullptr);
+        auto slot_of = [&](uint64_t k) {
+            size_t h = (size_t)((k * 0x9E3779B97F4A7C15ull) >> 20) & (cap - 1);
+            while (keys[h] != ~0ull && keys[h] != k) h = (h + 1) & (cap - 1);
+            return h;
+        };
+        for (size_t u = 0; u < V; ++u)
+            for (size_t i = 0; i < g_.adjacency[u].size(); ++i) {
+                const Edge &e = g_.adjacency[u][i];
+                const uint64_t x = ((uint64_t)u << 1) | (e.from_orient == '-');
+                const uint64_t y = ((uint64_t)e.to << 1) | (e.to_orient == '-');
+                const size_t h = slot_of((x << 32) | y);
+                if (keys[h] == ~0ull) {          // (a duplicate L line: the first edge counts)
+                    keys[h] = (x << 32) | y;
+                    vals[h] = &edge_w_[u][i];
+                }
+            }
+        const int64_t n = a.size();
+        const int64_t stride = std::max<int64_t>(1, (int64_t)a.steps.size() / 4000000);
+        for (int64_t k = 0; k < n; k += stride)
+            for (int32_t j = a.off[(size_t)k]; j + 1 < a.off[(size_t)k + 1]; ++j) {
+                const uint64_t x = (uint32_t)a.steps[(size_t)j], y = (uint32_t)a.steps[(size_t)j + 1];
+                size_t h = slot_of((x << 32) | y);
+                if (vals[h]) ++*vals[h];
+                h = slot_of(((y ^ 1u) << 32) | (x ^ 1u));          // the other strand
+                if (vals[h]) ++*vals[h];
+            }
     }
     ~Search()
     {
@@ -512,6 +561,8 @@ private:
         // < 0: ~index in the sub-batch scored in full)
         int32_t slot = -1, batch_at = 0;
         int32_t batch_depth = 0;   // ancestors inside the children sub-batch being collected
+        uint32_t edge_w = 0;       // alignments that take the edge this extension was made by (set_alignments)
+        float like = 0.f;          // collect_best: how likely the search is to pop this entry soon
     };
     struct Key {
         int32_t alt;
@@ -532,7 +583,9 @@ private:
         const uint32_t last_id = (uint32_t)(last & ~GFAL_STEP_OTHER) >> 1;
         const char last_orient = (last & 1) ? '-' : '+';
         const size_t n = ep.size();
-        for (const Edge &v : g_.adjacency[last_id]) {
+        const std::vector<Edge> &adj = g_.adjacency[last_id];
+        for (size_t vi = 0; vi < adj.size(); ++vi) {
+            const Edge &v = adj[vi];
             if (!fresh && last_orient != v.from_orient) continue;                         // :137
             const uint32_t allowed = allowance_[v.to];
             if (allowed == 0) continue;                                                   // :142-143
@@ -560,6 +613,7 @@ private:
             }
             c->uniques = e.uniques + (seen ? 0u : 1u);                                    // :153-160
             c->at_destination = v.to == dest_uid_;
+            if (!edge_w_.empty()) c->edge_w = edge_w_[last_id][vi];
             e.kids.push_back(std::move(c));
         }
     }
@@ -576,16 +630,9 @@ private:
     // its front entry, so the levels below it are what it asks for next.
     void collect(size_t budget)
     {
+        if (best_first_) return collect_best(budget);
         const double t0 = now_s();
-        batch_parents_.clear();
-        batch_off_.assign(1, 0);
-        batch_steps_.clear();
-        batch_slots_.clear();
-        ch_parent_.clear();
-        ch_step_.clear();
-        ch_slot_.clear();
-        ch_max_len_ = 2;
-        size_t n_paths = 0;
+        size_t n_paths = begin_collect();
         level_.clear();
         auto it = queue_.begin();
         // roots: the front entry always; further entries while there is room
@@ -599,37 +646,7 @@ private:
             next_.clear();
             for (Node *e : level_) {
                 if (n_paths >= budget && e != front) break;
-                if (!e->kids_batched) {
-                    if (!e->kids_made) make_kids(*e);     // (often made already: see make_ahead)
-                    e->kids_batched = true;
-                    batch_parents_.push_back(e);
-                    // search mode: a kid is scored from its parent when the parent is long
-                    // enough (no alignment longer than it) and is on the devices -- kept
-                    // there by an earlier batch, or itself a child of this one
-                    const bool from_parent = incr_ && e->len >= min_parent_ &&
-                                             !(e->last & GFAL_STEP_OTHER) &&
-                                             (e->slot >= 0 || e->batch_at > 0);
-                    for (auto &c : e->kids) {
-                        if (incr_ && !c->at_destination && c->len < GFAL_MAX_STEPS && c->len >= min_parent_)
-                            c->slot = take_slot();
-                        if (from_parent) {
-                            // (batch_at > 0: the parent is entry batch_at - 1 of this very sub-batch)
-                            ch_parent_.push_back(e->batch_at > 0 ? ~(e->batch_at - 1) : e->slot);
-                            ch_step_.push_back(c->last);
-                            ch_slot_.push_back(c->slot);
-                            ch_max_len_ = std::max(ch_max_len_, (int32_t)c->len);
-                            c->batch_at = (int32_t)ch_parent_.size();
-                            c->batch_depth = e->batch_at > 0 ? e->batch_depth + 1 : 0;
-                        } else {
-                            const std::vector<int32_t> &cp = c->path();
-                            batch_steps_.insert(batch_steps_.end(), cp.begin(), cp.end());
-                            batch_off_.push_back((int32_t)batch_steps_.size());
-                            batch_slots_.push_back(c->slot);
-                            c->batch_at = -(int32_t)batch_slots_.size();
-                        }
-                        ++n_paths;
-                    }
-                }
+                if (!e->kids_batched) n_paths += batch_kids(e);
                 // (a chain of in-batch parents is walked by one device thread per child:
                 // beyond 48 levels the rest of the dive waits for the next batch)
                 for (auto &c : e->kids)
@@ -638,6 +655,125 @@ private:
             }
             level_.swap(next_);
         }
+        finish_collect(n_paths, t0);
+    }
+
+    // The extensions of e join the batch being collected; returns how many.
+    size_t batch_kids(Node *e)
+    {
+        if (!e->kids_made) make_kids(*e);     // (often made already: see make_ahead)
+        e->kids_batched = true;
+        batch_parents_.push_back(e);
+        // search mode: a kid is scored from its parent when the parent is long
+        // enough (no alignment longer than it) and is on the devices -- kept
+        // there by an earlier batch, or itself a child of this one
+        const bool from_parent = incr_ && e->len >= min_parent_ &&
+                                 !(e->last & GFAL_STEP_OTHER) &&
+                                 (e->slot >= 0 || e->batch_at > 0);
+        for (auto &c : e->kids) {
+            if (incr_ && !c->at_destination && c->len < GFAL_MAX_STEPS && c->len >= min_parent_)
+                c->slot = take_slot();
+            if (from_parent) {
+                // (batch_at > 0: the parent is entry batch_at - 1 of this very sub-batch)
+                ch_parent_.push_back(e->batch_at > 0 ? ~(e->batch_at - 1) : e->slot);
+                ch_step_.push_back(c->last);
+                ch_slot_.push_back(c->slot);
+                ch_max_len_ = std::max(ch_max_len_, (int32_t)c->len);
+                c->batch_at = (int32_t)ch_parent_.size();
+                c->batch_depth = e->batch_at > 0 ? e->batch_depth + 1 : 0;
+            } else {
+                const std::vector<int32_t> &cp = c->path();
+                batch_steps_.insert(batch_steps_.end(), cp.begin(), cp.end());
+                batch_off_.push_back((int32_t)batch_steps_.size());
+                batch_slots_.push_back(c->slot);
+                c->batch_at = -(int32_t)batch_slots_.size();
+            }
+        }
+        return e->kids.size();
+    }
+
+    // Best-first speculation (GFALIGN_SPEC_POLICY=best; the default is the level-by-level walk
+    // above).  Breadth-first spends most of a batch on subtrees the search never enters -- 65 %
+    // of the candidates at config 3: every side branch of the dive is followed as deep as the
+    // dive itself.  Here every entry carries an estimate of how likely the search is to pop it
+    // soon: the front 1, an extension its parent's estimate times its share of the alignments
+    // that leave the parent's last step (edge_w_, squared: the search takes the best one), known
+    // keys instead where the extensions are scored already.  The likeliest entry whose extensions
+    // are not in a batch yet is expanded next, until the budget is spent or only long shots are
+    // left.  A candidate's counters do not depend on how it was chosen: same output.
+    // Measured (scripts/spec_policy.sh, -m 20000): a third fewer candidates (config 3: 42 071
+    // instead of 62 206, config 5: 27 810 instead of 40 233) but MORE batches (662 / 388 against
+    // 486 / 315; 510 / 310 with GFALIGN_SPEC_MIN_LIKE=0.0005) -- one wrong guess at a branch
+    // ends a batch's usefulness, where the breadth-first batch holds every branch -- and the
+    // loop is bound by the ~85 us a scoring call takes, not by the candidates in it: no faster,
+    // so it is not the default.
+    void collect_best(size_t budget)
+    {
+        const double t0 = now_s();
+        size_t n_paths = begin_collect();
+        spec_heap_.clear();
+        uint64_t seq = 0;
+        Node *front = queue_.begin()->second.get();
+        {
+            float like = 1.f;
+            size_t k = 0;
+            for (auto it = queue_.begin(); it != queue_.end() && k < 32; ++it, ++k) {
+                it->second->like = like;
+                spec_heap_.push_back(Spec{like, seq++, it->second.get()});
+                like = k == 0 ? 0.2f : like * 0.7f;       // (the other queue entries wait for the dive to fail)
+            }
+            std::make_heap(spec_heap_.begin(), spec_heap_.end());
+        }
+        while (!spec_heap_.empty()) {
+            std::pop_heap(spec_heap_.begin(), spec_heap_.end());
+            Node *e = spec_heap_.back().n;
+            spec_heap_.pop_back();
+            if (e != front && (n_paths >= budget || e->like < min_like_)) break;
+            if (!e->kids_batched) n_paths += batch_kids(e);
+            if (e->kids.empty()) continue;
+            // the extensions' shares
+            double total = 0;
+            int32_t best_key = INT32_MAX;
+            for (auto &c : e->kids) {
+                if (e->kids_scored) best_key = std::min(best_key, key_of(*c));
+                const double w = (double)c->edge_w + 1.0;
+                total += w * w;
+            }
+            bool best_taken = false;
+            for (auto &c : e->kids) {
+                if (c->at_destination || c->len >= GFAL_MAX_STEPS || c->batch_depth >= max_depth_) continue;
+                float share;
+                if (e->kids_scored) {       // (keys known: the first of the smallest is popped first)
+                    const bool best = !best_taken && key_of(*c) == best_key;
+                    best_taken |= best;
+                    share = best ? 0.9f : 0.1f / (float)e->kids.size();
+                } else {
+                    const double w = (double)c->edge_w + 1.0;
+                    share = (float)(w * w / total);
+                }
+                c->like = e->like * share;
+                spec_heap_.push_back(Spec{c->like, seq++, c.get()});
+                std::push_heap(spec_heap_.begin(), spec_heap_.end());
+            }
+        }
+        finish_collect(n_paths, t0);
+    }
+
+    size_t begin_collect()
+    {
+        batch_parents_.clear();
+        batch_off_.assign(1, 0);
+        batch_steps_.clear();
+        batch_slots_.clear();
+        ch_parent_.clear();
+        ch_step_.clear();
+        ch_slot_.clear();
+        ch_max_len_ = 2;
+        return 0;
+    }
+
+    void finish_collect(size_t n_paths, double t0)
+    {
         if (dump_ && n_paths) {   // GFALIGN_DUMP_BATCHES: the candidate batches (full paths), for benchmarks
             std::vector<int32_t> off{0}, steps;
             for (Node *e : batch_parents_)
@@ -809,6 +945,18 @@ private:
     }
     bool in_flight_ = false;
     FILE *dump_ = nullptr;
+    // speculation policy (collect / collect_best)
+    std::vector<std::vector<uint32_t>> edge_w_;      // [uid][edge of g_.adjacency[uid]]
+    bool best_first_ = false;
+    float min_like_ = 0.004f;
+    int max_depth_ = 48;
+    struct Spec {
+        float like;
+        uint64_t seq;
+        Node *n;
+        bool operator<(const Spec &o) const { return like != o.like ? like < o.like : seq > o.seq; }
+    };
+    std::vector<Spec> spec_heap_;
 };
 
 }  // namespace gfal

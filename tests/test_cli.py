@@ -259,6 +259,11 @@ def test_search_on_a_synthetic_tangle_matches_oracle(cli, gpu, tmp_path):
         rc, out, err = run(cli, base, env={"GFALIGN_SPECULATE": spec, "GFALIGN_PREFETCH": "1"})
         assert rc == 0, err
         assert out == outs[0]
+    # nor does the speculation policy (best-first by the alignments' support of the edges)
+    for spec in ("7", "128"):
+        rc, out, err = run(cli, base, env={"GFALIGN_SPECULATE": spec, "GFALIGN_SPEC_POLICY": "best"})
+        assert rc == 0, err
+        assert out == outs[0]
     # alignments sharded over three scorers (all on this box's one GPU): same bytes
     rc, out, err = run(cli, base + ["--devices", "3"], env={"GFALIGN_SHARE_DEVICE": "1"})
     assert rc == 0, err
