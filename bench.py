@@ -17,6 +17,7 @@ Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for how `roofline`,
 `cpu_baseline` and `search_mode` are defined.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -330,6 +331,10 @@ def main():
     # the timed region: HIP events around the dominant kernel only (level 2: two events per
     # step; the full set of phase events costs a step ~3 %)
     sc.set_profiling(2)
+    # (no cyclic collection of the interpreter inside the timed steps: a generation-2 pass is
+    # ~40 ms of host time, scripts/small_shard_probe.py)
+    gc.collect()
+    gc.disable()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
@@ -341,6 +346,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
+    gc.enable()
     sc.sync_status()
     info = sc.info()
     # the phases of a step (scan phase, exact DP, whole call): a few more steps with every

@@ -2,13 +2,18 @@
 (10 000 paths, device-resident) and a search-sized batch (128 paths, blocking
 call from host buffers) against 1/N of the alignments, N = 1, 2, 4, 8.  The
 N-GPU step is this plus one all-reduce of uint32[3P] (120 KB / 1.5 KB)."""
-import os, sys, time
+import gc, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from gfalign_amd import synth
 from gfalign_amd.scorer import Scorer
 
+# (the interpreter's cyclic collector off: one ~40 ms generation-2 collection used to land, at a
+# deterministic allocation count, inside the 50-call loop of the last shard of the 4-way split --
+# the "0.97 / 1.03 / 0.93 ms" outlier of the round-2 and mid-round-3 records; the device time of
+# those calls was 0.21 ms like its neighbours', scripts/small_shard_probe.py)
+gc.disable()
 t = synth.make(sys.argv[1] if len(sys.argv) > 1 else "config3")
 dev = torch.device("cuda", 0)
 P = t.P
