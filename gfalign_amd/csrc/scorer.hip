@@ -4401,7 +4401,17 @@ struct Scan3Args {
     uint32_t h_slots;            // table slots of a workgroup (power of two)
     uint32_t *counts;
     uint32_t *counts_dbg;        // the scorer's status words (diagnostic builds count into words 4..7)
+    const uint32_t *ct_mult;     // alignments per content index (weights summed): the subpath pairs are counted from the lists
 };
+
+// GFAL_SCAN3_LG (default on): the good pairs that are subpaths are counted from the tile's
+// lists -- {content, paths} x the content's multiplicity, once per (tile, length) -- and the
+// item loop counts every pair that passes the filter as bad: the probe of the table is left
+// to the few waves with a lane that can have a start overhang (its alignment touches the
+// tile's first node).  0: every lane probes and counts its own good pairs (round 3's first form).
+#ifndef GFAL_SCAN3_LG
+#define GFAL_SCAN3_LG 1
+#endif
 
 typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
 typedef __attribute__((address_space(3))) const unsigned long long lds_cu64;
@@ -4499,6 +4509,34 @@ struct Acc3 {
                     good += dg;
                     bad += db;
                 }
+            }
+        }
+    }
+    // the same for pairs that are all bad (no tile path is shorter than the alignments: the
+    // usual case when the subpath pairs are counted from the lists)
+    __device__ __forceinline__ void add_bad(uint32_t bad_mask, const Tile3 &tv, uint32_t w, int lane)
+    {
+        const bool isb = (uint32_t)__builtin_popcount(bad_mask) > tv.half;
+        const lanemask mb = WAVE_MASK(isb);
+        if constexpr (W) fb += isb ? w : 0u;
+        else fb += (uint32_t)__popcll(mb);
+        const uint32_t xb = bad_mask ^ (isb ? tv.sub_mask : 0u);
+        lanemask any_x = WAVE_MASK(xb != 0u);
+        asm volatile("" : "+s"(any_x));
+        if (__builtin_expect(any_x != 0ull, 0)) {
+            uint32_t u = wave_or_dpp(xb);
+            while (u) {
+                const int p = __builtin_ctz(u);
+                u &= u - 1u;
+                const bool eb = ((xb >> p) & 1u) != 0u;
+                uint32_t db;
+                if constexpr (W) {
+                    db = wave_add_dpp(eb ? (isb ? 0u - w : w) : 0u);
+                } else {
+                    const lanemask b = WAVE_MASK(eb);
+                    db = (uint32_t)__popcll(b & ~mb) - (uint32_t)__popcll(b & mb);
+                }
+                if (lane == p) bad += db;
             }
         }
     }
@@ -4695,8 +4733,33 @@ __device__ __forceinline__ void scan3_decide(const Tile3 &tv, uint32_t key, uint
     acc.good += good_mask ^ open;
     return;
 #endif
+#if GFAL_SCAN3_LG
+    // (the subpath pairs among `pass` are taken back out of `bad` by the list count)
+    const uint32_t pass = pm & tv.sub_mask;
+    acc.add(pass & tv.gt_mask, pass & ~tv.gt_mask, tv, w, lane);
+#else
     acc.add(good_mask, open, tv, w, lane);
+#endif
 }
+
+#if GFAL_SCAN3_LG
+// The hot path of an item: filter and count; the table is asked only when a lane can have a
+// start overhang at all.
+template <bool W>
+__device__ __forceinline__ void scan3_count(const Tile3 &tv, uint32_t key, uint32_t w, uint32_t pm,
+                                            int src, lanemask &tri, int lane, Acc3<W> &acc)
+{
+    const uint32_t pass = pm & tv.sub_mask;
+    const uint32_t todo = pass & ~tv.gt_mask;
+    if (__builtin_expect(WAVE_ANY(todo != 0u && (int32_t)pm >= 0), 0)) {
+        const uint2 e = lds_entry(tv.tab_base + ((key & tv.h_mask) << 3));
+        scan3_decide<W>(tv, key, w, pm, e, src, tri, lane, acc);
+        return;
+    }
+    if (tv.gt_mask == 0u) acc.add_bad(todo, tv, w, lane);
+    else acc.add(pass & tv.gt_mask, todo, tv, w, lane);
+}
+#endif
 
 template <int P0, bool W, bool NMG>
 __device__ __forceinline__ void scan3_item(const Tile3 &tv, const Item3Regs<P0, W> &r, lanemask &tri, int lane,
@@ -4709,6 +4772,15 @@ __device__ __forceinline__ void scan3_item(const Tile3 &tv, const Item3Regs<P0, 
     acc.good += x;
     return;
 #endif
+#if GFAL_SCAN3_LG
+    uint32_t pm = 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 0; k < P0; ++k) {
+        pm &= nm_read<NMG>(tv, r.np[k] & 0xFFFFu);
+        pm &= nm_read<NMG>(tv, r.np[k] >> 16);
+    }
+    scan3_count<W>(tv, r.key, r.w, pm, r.src, tri, lane, acc);
+#else
     // the probe goes out together with the node-mask reads: one LDS round trip
     const uint2 e = lds_entry(tv.tab_base + ((r.key & tv.h_mask) << 3));
     uint32_t pm = 0xFFFFFFFFu;
@@ -4722,6 +4794,7 @@ __device__ __forceinline__ void scan3_item(const Tile3 &tv, const Item3Regs<P0, 
     return;
 #endif
     scan3_decide<W>(tv, r.key, r.w, pm, e, r.src, tri, lane, acc);
+#endif
 }
 
 // A marked item again, now with the overhang test: the pairs it hands to the exact DP
@@ -4812,14 +4885,20 @@ __device__ __forceinline__ void scan3_items(const Scan3Args &a, const Tile3 &tv,
                 const uint32_t *pp = a.rec3 + ((size_t)sg.r3_base + (size_t)(it - sg.item_lo) * R) * WAVE + ulane;
                 const uint32_t key = pp[0];
                 const uint32_t w = W ? pp[(size_t)(P0rt + 1) * WAVE] : 1u;
+#if !GFAL_SCAN3_LG
                 const uint2 e = lds_entry(tv.tab_base + ((key & tv.h_mask) << 3));
+#endif
                 uint32_t pm = 0xFFFFFFFFu;
                 for (int k = 0; k < P0rt; ++k) {
                     const uint32_t x = pp[(size_t)(k + 1) * WAVE];
                     pm &= nm_read<NMG>(tv, x & 0xFFFFu);
                     pm &= nm_read<NMG>(tv, x >> 16);
                 }
+#if GFAL_SCAN3_LG
+                scan3_count<W>(tv, key, w, pm, src, tri, lane, acc);
+#else
                 scan3_decide<W>(tv, key, w, pm, e, src, tri, lane, acc);
+#endif
             }
         }
         if (tri != 0 && lane == 0) {      // (settled by scan3_fixups when the wave's items are done)
@@ -4959,6 +5038,36 @@ __global__ __launch_bounds__(SCAN2_THREADS, SCAN2_WAVES_PER_SIMD) void k_scan3(S
         tv.sub_mask = range;
         tv.half = (uint32_t)__builtin_popcount(tv.sub_mask) / 2u;
         tv.gt_mask = (uint32_t)WAVE_MASK(lane >= t0 && lane < t1 && hdr_n < M);
+#if GFAL_SCAN3_LG
+        // The subpath pairs of this (tile, length), counted from the table: every entry is one
+        // content with the paths that contain it (windows merged), and ct_mult alignments carry
+        // it.  The item loops of the segment's chunks count those pairs as bad; every chunk
+        // settles the contents a hash of the index assigns to it (the same in every workgroup,
+        // whatever slot the entry took there).  Lane p adds up path p: an entry's mask and
+        // multiplicity are broadcast from the lane that read it -- no atomics.  (Paths shorter
+        // than the alignments have no windows; their passing pairs are good, src/alignments.cpp:500.)
+        {
+            uint32_t lg = 0;
+            const uint32_t n_chunks = sg.n_chunks;
+            for (uint32_t sl0 = (uint32_t)wave * WAVE; sl0 < a.h_slots; sl0 += SCAN2_THREADS) {
+                const uint32_t sl = sl0 + (uint32_t)lane;
+                const uint2 e = lds_entry(tv.tab_base + (sl << 3));
+                uint32_t bits = 0, mult = 0;
+                if (e.x != KEY_EMPTY && ((((e.x * 0x9E3779B1u) >> 16) * n_chunks) >> 16) == (uint32_t)chunk) {
+                    bits = e.y & range & ~tv.gt_mask;
+                    if (bits) mult = a.ct_mult[e.x];
+                }
+                for (lanemask todo = WAVE_MASK(bits != 0u); todo; todo &= todo - 1ull) {
+                    const int src = __builtin_ctzll(todo);
+                    const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)bits, src);
+                    const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)mult, src);
+                    lg += ((b >> lane) & 1u) ? m : 0u;
+                }
+            }
+            cnt_good += lg;
+            cnt_bad -= lg;
+        }
+#endif
         Seg3 sgl = sg;
         if (a.debug == 1) sgl.item_hi = sgl.item_lo;      // timing probe: no items
         Acc3<W> acc;
@@ -6268,6 +6377,7 @@ static int launch_scan3(gfal_scorer *s, hipStream_t st, const Items &items, cons
     a3.n_segs_total = n_segs;
     a3.h_slots = h_slots;
     a3.counts = d_counts;
+    a3.ct_mult = s->d_ct_mult;
     a3.counts_dbg = s->d_status;
     // chunks per segment: in proportion to the segment's items (see k_scan2's launch)
     int y_want = (want_groups + n_tiles - 1) / n_tiles;
