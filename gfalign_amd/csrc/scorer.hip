@@ -5047,15 +5047,20 @@ __global__ __launch_bounds__(SCAN2_THREADS, SCAN2_WAVES_PER_SIMD) void k_scan3(S
         // multiplicity are broadcast from the lane that read it -- no atomics.  (Paths shorter
         // than the alignments have no windows; their passing pairs are good, src/alignments.cpp:500.)
         {
-            uint32_t lg = 0;
+            uint32_t lg = 0, all_sum = 0;
             const uint32_t n_chunks = sg.n_chunks;
+            const uint32_t all = range & ~tv.gt_mask;       // (most windows are shared by every path of the tile)
             for (uint32_t sl0 = (uint32_t)wave * WAVE; sl0 < a.h_slots; sl0 += SCAN2_THREADS) {
                 const uint32_t sl = sl0 + (uint32_t)lane;
                 const uint2 e = lds_entry(tv.tab_base + (sl << 3));
                 uint32_t bits = 0, mult = 0;
                 if (e.x != KEY_EMPTY && ((((e.x * 0x9E3779B1u) >> 16) * n_chunks) >> 16) == (uint32_t)chunk) {
-                    bits = e.y & range & ~tv.gt_mask;
+                    bits = e.y & all;
                     if (bits) mult = a.ct_mult[e.x];
+                    if (bits == all) {       // every path: summed per lane, spread once at the end
+                        all_sum += mult;
+                        bits = 0;
+                    }
                 }
                 for (lanemask todo = WAVE_MASK(bits != 0u); todo; todo &= todo - 1ull) {
                     const int src = __builtin_ctzll(todo);
@@ -5064,6 +5069,8 @@ __global__ __launch_bounds__(SCAN2_THREADS, SCAN2_WAVES_PER_SIMD) void k_scan3(S
                     lg += ((b >> lane) & 1u) ? m : 0u;
                 }
             }
+            all_sum = wave_add_dpp(all_sum);
+            lg += ((all >> lane) & 1u) ? all_sum : 0u;
             cnt_good += lg;
             cnt_bad -= lg;
         }
