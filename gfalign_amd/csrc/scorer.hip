@@ -4970,7 +4970,6 @@ __global__ __launch_bounds__(SCAN2_THREADS, SCAN2_WAVES_PER_SIMD) void k_scan3(S
     Tile3 tv;
     tv.path0 = (a.tile0 + tile_rel) * a.tile;
     tv.tile_paths = min(a.tile, a.n_paths - tv.path0);
-    tv.h_mask = a.h_slots - 1u;
     tv.nm_shift = a.nm_shift;
     // LDS: node masks first (address = the record's byte offset: no base to add), then the table
     uint32_t *tab = lds32 + (NMG ? 0 : v2p);
@@ -4994,7 +4993,12 @@ __global__ __launch_bounds__(SCAN2_THREADS, SCAN2_WAVES_PER_SIMD) void k_scan3(S
     if (lane < tv.tile_paths) hdr_n = (int)a.tile_hdr[(size_t)tile_rel * T3_THDR_WORDS + lane];
     const uint32_t count = a.list_count[(size_t)tile_rel * a.n_segs_total + a.seg0 + seg];
     const uint2 *list = a.list + ((size_t)tile_rel * a.n_segs_total + a.seg0 + seg) * a.stride;
-    const uint32_t cap = a.h_slots / 2;
+    // the table: as many slots as four times the list's entries (a short tile, a rare length:
+    // less to clear and to walk), at most what the launch has room for
+    uint32_t h_slots = 1024;
+    while (h_slots < 4u * count && h_slots < a.h_slots) h_slots <<= 1;
+    tv.h_mask = h_slots - 1u;
+    const uint32_t cap = h_slots / 2;
 
     uint32_t cnt_good = 0, cnt_bad = 0;      // lane p: totals of tile path p over all passes
     // Passes over the tile's paths: usually one.  The window list of unrelated paths may
@@ -5006,7 +5010,7 @@ __global__ __launch_bounds__(SCAN2_THREADS, SCAN2_WAVES_PER_SIMD) void k_scan3(S
         __syncthreads();                     // (the previous pass's probes are done)
         {
             uint4 *t4 = reinterpret_cast<uint4 *>(tab);
-            for (uint32_t i = tid; i < a.h_slots / 2; i += SCAN2_THREADS)
+            for (uint32_t i = tid; i < h_slots / 2; i += SCAN2_THREADS)
                 t4[i] = make_uint4(KEY_EMPTY, 0u, KEY_EMPTY, 0u);
             if (tid < 2) misc[tid] = 0;      // [0] entries [1] overflow
             if (tid < SCAN2_WAVES * SCAN3_GROUPS * 2) tv.tri_lds[tid] = 0;
@@ -5050,7 +5054,7 @@ __global__ __launch_bounds__(SCAN2_THREADS, SCAN2_WAVES_PER_SIMD) void k_scan3(S
             uint32_t lg = 0, all_sum = 0;
             const uint32_t n_chunks = sg.n_chunks;
             const uint32_t all = range & ~tv.gt_mask;       // (most windows are shared by every path of the tile)
-            for (uint32_t sl0 = (uint32_t)wave * WAVE; sl0 < a.h_slots; sl0 += SCAN2_THREADS) {
+            for (uint32_t sl0 = (uint32_t)wave * WAVE; sl0 < h_slots; sl0 += SCAN2_THREADS) {
                 const uint32_t sl = sl0 + (uint32_t)lane;
                 const uint2 e = lds_entry(tv.tab_base + (sl << 3));
                 uint32_t bits = 0, mult = 0;

@@ -5,4 +5,5 @@ for e in "X=1" "X=2"; do
 env $e $B 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$e', d['ms_per_step'], d['config'].get('counter_checksum'), d['roofline']['kernel_ms'])"
 done
 python3 scripts/scan_probe.py config5 "" 2>&1 | grep -v amdgpu.ids
-timeout -k 10 900 python -m pytest tests/test_gpu_scan2.py tests/test_gpu_fuzz.py tests/test_gpu_parity.py -x -q -m gpu 2>&1 | tail -n 4
+python3 scripts/shard_probe.py 8 8192 2>&1 | grep shard
+timeout -k 10 900 python -m pytest tests/test_gpu_scan2.py tests/test_gpu_fuzz.py -x -q -m gpu 2>&1 | tail -n 4
