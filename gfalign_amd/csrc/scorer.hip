@@ -7,19 +7,28 @@
 //
 //   create      alignments -> dense local node ids, bucketed by length,
 //               sorted by content, stored as 64-alignment "items" in
-//               step-major order (one coalesced 128-B load per step per wave).
+//               step-major order (one coalesced 128-B load per step per wave);
+//               k_ct_build numbers the distinct contents (content table) and
+//               every lane learns the number of its own.
 //   k_prep      one wave per candidate path: builds the path's lookup image
 //               (first-occurrence table by node, occurrence chain, steps) in
 //               LDS and writes it to HBM; also the `unaligned` counter.
-//   k_scan2     the dominant kernel: workgroup = (tile of T <= 8 paths) x (one
-//               alignment length) x (a chunk of its items); every window of the
-//               tile's paths sits in a hash table in LDS, so a lane's alignment
-//               is tested against ALL paths of the tile with one probe.  One
-//               launch per alignment-length group (spill-free instantiations).
+//   k_tile_masks, k_overhang, k_tile   (round 3; batches of >= 512 paths) per tile of
+//               31 paths: node masks, and every window of the tile's paths looked
+//               up in the content table ONCE -> per alignment length a list of
+//               {content number, paths that contain it}.
+//   k_scan3     the dominant kernel: workgroup = (tile) x (one alignment length) x
+//               (a chunk of its items).  The subpath pairs are counted from the
+//               tile's list x the contents' multiplicities; a lane ANDs its nodes'
+//               masks (the filter for 31 paths at once) and counts who passes;
+//               only lanes that can have a start overhang ask the LDS table
+//               (keyed by content number) and take the exact overhang test.
+//   k_scan2     round 2's scan (windows of 8 paths hashed into an LDS table,
+//               steps compared per item): batches of 96..511 paths.
 //   k_scan      the same decisions by occurrence-chain walks: workgroup = T path
 //               images staged in LDS x one chunk of items; the rare alignment
 //               lengths and batches of a few dozen paths.  Pairs the cheap rules
-//               of either kernel cannot decide go to a worklist.
+//               of these kernels cannot decide go to a worklist.
 //   k_wl_*      counting sort of the worklist by (length class, path).
 //   k_dp_regs   exact Needleman-Wunsch + traceback-exit propagation for the
 //               worklist ("start-overhang" pairs): one pair per lane, rows in
@@ -6850,8 +6859,11 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
         // the device only) decides which family returns at once
         if (!dp_small) {
         const bool big = n_paths >= 2048;
-        hipLaunchKernelGGL(k_dp_sys<4>, dim3(DP_SYS_BLOCKS), dim3(DP_THREADS), 0, st, d);
+        // (a big batch: the throughput kernel first, here too -- the other family's workgroups
+        // return at once, but a launch in front of the one with the work is 6-12 us of the step)
+        if (!big) hipLaunchKernelGGL(k_dp_sys<4>, dim3(DP_SYS_BLOCKS), dim3(DP_THREADS), 0, st, d);
         hipLaunchKernelGGL((k_dp_regs<4, 0>), dim3(DP_REG_BLOCKS), dim3(DP_THREADS), 0, st, d);
+        if (big) hipLaunchKernelGGL(k_dp_sys<4>, dim3(DP_SYS_BLOCKS), dim3(DP_THREADS), 0, st, d);
         if (s->max_aln_len > 4) {
             hipStream_t s0 = side(0);
             // (a big batch: the throughput kernel first -- behind the other family's launch,
