@@ -13,7 +13,7 @@
 //   k_prep      one wave per candidate path: builds the path's lookup image
 //               (first-occurrence table by node, occurrence chain, steps) in
 //               LDS and writes it to HBM; also the `unaligned` counter.
-//   k_tile_masks, k_overhang, k_tile   (round 3; batches of >= 512 paths) per tile of
+//   k_tile_masks, k_overhang, k_tile   (round 3; batches of >= 320 paths) per tile of
 //               31 paths: node masks, and every window of the tile's paths looked
 //               up in the content table ONCE -> per alignment length a list of
 //               {content number, paths that contain it}.
@@ -24,7 +24,7 @@
 //               only lanes that can have a start overhang ask the LDS table
 //               (keyed by content number) and take the exact overhang test.
 //   k_scan2     round 2's scan (windows of 8 paths hashed into an LDS table,
-//               steps compared per item): batches of 96..511 paths.
+//               steps compared per item): batches of 96..319 paths.
 //   k_scan      the same decisions by occurrence-chain walks: workgroup = T path
 //               images staged in LDS x one chunk of items; the rare alignment
 //               lengths and batches of a few dozen paths.  Pairs the cheap rules
@@ -6650,9 +6650,10 @@ static int score_device_impl(gfal_scorer *s, const int32_t *d_path_off,
         // k_scan3 (content identities, 31 paths per tile) takes what k_scan2 took unless
         // GFAL_SCAN=2 asks for the older kernel
         // or the batch is small: k_tile works a tile through in one workgroup, ~0.1 ms whatever
-        // the batch, which a few hundred paths do not pay back (scripts/small_batch_probe.py:
-        // 128 paths 0.12 ms with k_scan2 against 0.24 ms, even at 512, 4096 paths 0.50 against 1.61)
-        int scan3_min_paths = 512;
+        // the batch, which a couple of hundred paths do not pay back (scripts/small_batch_probe.py,
+        // scan phase with k_scan2 / with k_tile + k_scan3: 128 paths 0.15 / 0.22 ms, 256 paths
+        // 0.22 / 0.24, 384 paths 0.30 / 0.24, 1024 paths k_scan3 0.29 ms)
+        int scan3_min_paths = 320;
         if (const char *env = getenv("GFAL_SCAN3_MIN_PATHS")) scan3_min_paths = atoi(env);
         const bool use3 = n_segs2 > 0 && !children && s->scan_mode != 2 &&
                           (n_paths >= scan3_min_paths || s->scan_mode == 3);
