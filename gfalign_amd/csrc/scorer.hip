@@ -4862,12 +4862,17 @@ __device__ __forceinline__ void scan3_items(const Scan3Args &a, const Tile3 &tv,
         if (todo == 0) continue;
         lanemask tri = 0;                // items of this group that need the overhang test
         if constexpr (P0 > 0) {
+            // the record of item `src` of this group: the group's first record + src * a fixed
+            // stride (one scalar multiply-add per item instead of the address from scratch: the
+            // scalar unit is as busy as the VALUs in this loop)
+            constexpr uint32_t RW = (uint32_t)(P0 + 1 + (W ? 1 : 0));
+            const uint32_t *gbase = a.rec3 + ((size_t)sg.r3_base + (size_t)(it0 - (int)sg.item_lo) * RW) * WAVE;
+            asm volatile("" : "+s"(gbase));
+            const uint32_t gstep = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)item_stride * RW * WAVE));      // dwords
             auto load_item = [&](int src_in, Item3Regs<P0, W> &r) {
                 const int src = __builtin_amdgcn_readfirstlane(src_in);
-                const uint32_t it = (uint32_t)(it0 + src * item_stride);
                 r.src = src;
-                const GLOBAL_AS uint32_t *pp =
-                    sgpr_ptr(a.rec3 + ((size_t)sg.r3_base + (size_t)(it - sg.item_lo) * (P0 + 1 + (W ? 1 : 0))) * WAVE) + ulane;
+                const GLOBAL_AS uint32_t *pp = sgpr_ptr(gbase + (size_t)((uint32_t)src * gstep)) + ulane;
                 r.key = pp[0];
 #pragma unroll
                 for (int k = 0; k < P0; ++k) r.np[k] = pp[(k + 1) * WAVE];
