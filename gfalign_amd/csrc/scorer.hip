@@ -4868,29 +4868,32 @@ __device__ __forceinline__ void scan3_items(const Scan3Args &a, const Tile3 &tv,
             constexpr uint32_t RW = (uint32_t)(P0 + 1 + (W ? 1 : 0));
             const uint32_t *gbase = a.rec3 + ((size_t)sg.r3_base + (size_t)(it0 - (int)sg.item_lo) * RW) * WAVE;
             asm volatile("" : "+s"(gbase));
-            const uint32_t gstep = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)item_stride * RW * WAVE));      // dwords
-            auto load_item = [&](int src_in, Item3Regs<P0, W> &r) {
-                const int src = __builtin_amdgcn_readfirstlane(src_in);
+            const uint32_t gstep = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)item_stride * RW * WAVE * 4u));      // bytes
+            // (the rank of the mask's first item; an empty mask -- one item too far ahead --
+            // loads the group's first record again: s_ff1 gives -1 for it)
+            auto load_item = [&](lanemask m, Item3Regs<P0, W> &r) {
+                int src;
+                asm("s_ff1_i32_b64 %0, %1" : "=s"(src) : "s"(m));
+                src = max(src, 0);
                 r.src = src;
-                const GLOBAL_AS uint32_t *pp = sgpr_ptr(gbase + (size_t)((uint32_t)src * gstep)) + ulane;
+                const GLOBAL_AS uint32_t *pp =
+                    sgpr_ptr(reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(gbase) + (uint32_t)src * gstep)) + ulane;
                 r.key = pp[0];
 #pragma unroll
                 for (int k = 0; k < P0; ++k) r.np[k] = pp[(k + 1) * WAVE];
                 r.w = W ? pp[(P0 + 1) * WAVE] : 1u;
             };
             Item3Regs<P0, W> ra, rb;
-            load_item(__builtin_ctzll(todo), ra);
+            load_item(todo, ra);
             while (true) {
-                lanemask rest = todo & (todo - 1);
-                load_item(__builtin_ctzll(rest ? rest : todo), rb);
+                const lanemask rest = todo & (todo - 1);
+                load_item(rest, rb);
                 scan3_item<P0, W, NMG>(tv, ra, tri, lane, acc);
                 if (rest == 0) break;
-                todo = rest;
-                rest = todo & (todo - 1);
-                load_item(__builtin_ctzll(rest ? rest : todo), ra);
+                todo = rest & (rest - 1);
+                load_item(todo, ra);
                 scan3_item<P0, W, NMG>(tv, rb, tri, lane, acc);
-                if (rest == 0) break;
-                todo = rest;
+                if (todo == 0) break;
             }
         } else {      // the longer alignments are rare: no second register set for them
             for (; todo != 0; todo &= todo - 1) {
