@@ -3138,14 +3138,38 @@ __global__ __launch_bounds__(1024) void k_inv_scan(const uint32_t *__restrict__ 
 // rec[idx] = {representative lane, m | step 0 << 16, steps 1..2, steps 3..4}: what a lookup
 // compares in one 16-byte load (k_tile); idx, the identity of the lane's content, goes into
 // the lane's item record (k_scan3)
+constexpr int PAIR_BITS_LOG2 = 22;            // 4 M bits = 512 KB (L2-resident)
+__device__ __forceinline__ uint32_t pair_bit_index(uint32_t x, uint32_t y)
+{
+    return (((x << 16) | (y & 0xFFFFu)) * 0x9E3779B1u) >> (32 - PAIR_BITS_LOG2);
+}
+__device__ __forceinline__ bool pair_present(const uint32_t *bits, uint32_t x, uint32_t y)
+{
+    const uint32_t i = pair_bit_index(x, y);
+    return (bits[i >> 5] >> (i & 31u)) & 1u;
+}
+
 __global__ void k_ct_build(Items items, const int32_t *__restrict__ slot_orig, uint32_t n_slots,
                            const uint32_t *__restrict__ item_hash, uint32_t *__restrict__ key,
                            uint32_t *__restrict__ hash, uint32_t *__restrict__ mult, uint32_t mask,
                            uint4 *__restrict__ rec, uint32_t *__restrict__ rec3,
-                           const uint32_t *__restrict__ item_r3)
+                           const uint32_t *__restrict__ item_r3, uint32_t *__restrict__ pair_bits)
 {
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= n_slots || slot_orig[slot] < 0) return;
+    {   // the lane's pairs of consecutive steps, both strands (ContentTable::pair_bits)
+        const uint32_t it = slot >> 6;
+        const int m = items.len[it];
+        const uint16_t *bp = items.steps + (size_t)items.base[it] * WAVE + (slot & 63u);
+        uint32_t x = m > 0 ? (uint32_t)bp[0] : 0u;
+        for (int k = 1; k < m; ++k) {
+            const uint32_t y = bp[(size_t)k * WAVE];
+            const uint32_t i1 = pair_bit_index(x, y), i2 = pair_bit_index(y ^ 1u, x ^ 1u);
+            atomicOr(&pair_bits[i1 >> 5], 1u << (i1 & 31u));
+            atomicOr(&pair_bits[i2 >> 5], 1u << (i2 & 31u));
+            x = y;
+        }
+    }
     // the lane's key: first dword of its item record (k_scan3)
     uint32_t *my_key = rec3 + (size_t)item_r3[slot >> 6] * WAVE + (slot & 63u);
     const uint32_t h = item_hash[slot];
@@ -3744,6 +3768,10 @@ constexpr int T3_CT_INLINE = 5;            // steps of an alignment a content-ta
 struct ContentTable {
     const uint4 *rec;       // {representative lane or CT_EMPTY, m | s0 << 16, s1 | s2 << 16, s3 | s4 << 16}
     uint32_t mask;
+    // one bit per hashed pair of consecutive steps that occurs in some alignment, on either
+    // strand (a Bloom filter with one hash: no false negatives).  A window that contains a
+    // pair no alignment has cannot be an alignment's content: k_tile skips its lookups.
+    const uint32_t *pair_bits;
 };
 
 struct TileArgs {
@@ -4014,6 +4042,42 @@ __device__ __forceinline__ void t3_windows_at(const TileArgs &a, const uint16_t 
         r8[0] = lo.x, r8[1] = lo.y, r8[2] = lo.z, r8[3] = lo.w;
         r8[4] = hi.x, r8[5] = hi.y, r8[6] = hi.z, r8[7] = hi.w;
         run_ref = (int)(hi.w >> 24);
+    } else {
+        // a position with windows of its own (this path and the tile's first path differ
+        // nearby): where the path still agrees with the batch's longest path -- it is the
+        // tile's FIRST path that carries the substituted step -- the indices are the reference's
+        const uint16_t *Fr = a.images + a.L.step_at() + f;      // image slot 0
+        const int n_ref = (int)a.images[a.L.len_at()];
+        int agree = 0;
+        bool same = true;
+#pragma unroll
+        for (int k = 0; k < T3_REG_M; ++k) {
+            const uint32_t r = f + k < n_ref ? (uint32_t)Fr[k] : 0xFFFEu;
+            same = same && r == c[k] && c[k] < STEP_NOMATCH;
+            agree += same ? 1 : 0;
+        }
+        run_ref = agree;
+    }
+    // Lengths from skip_from on need no lookup: the window then holds a pair of consecutive
+    // steps that no alignment has on either strand (ContentTable::pair_bits) -- what a
+    // substituted step nearly always brings.  The pairs around the first step that is not
+    // the reference's (position run_ref of the window; for the tile's first path: where it
+    // leaves the reference) are asked once for all lengths.
+    int skip_from = T3_REG_M + 1;
+    if (run_ref < m_real && run_ref < T3_REG_M) {
+        const int d = run_ref;
+        bool have1 = true, have2 = true;      // (c[d - 1], c[d]) and (c[d], c[d + 1])
+        uint32_t cd = 0, cm = 0, cp = 0;
+#pragma unroll
+        for (int k = 0; k < T3_REG_M; ++k) {
+            cd = k == d ? c[k] : cd;
+            cm = k == d - 1 ? c[k] : cm;
+            cp = k == d + 1 ? c[k] : cp;
+        }
+        if (d > 0) have1 = pair_present(a.ct.pair_bits, cm, cd);
+        if (d + 1 < m_real) have2 = pair_present(a.ct.pair_bits, cd, cp);
+        if (!have1) skip_from = d + 1;                    // every window that reaches position d
+        else if (!have2) skip_from = d + 2;               // every window that reaches position d + 1
     }
     T3Pend pend[T3_PEND];
 #pragma unroll
@@ -4041,6 +4105,7 @@ __device__ __forceinline__ void t3_windows_at(const TileArgs &a, const uint16_t 
             t3_append(&cnt[s], out, kr != KEY_EMPTY && kr != kf, make_uint2(kr, bits));
             continue;
         }
+        if (M >= skip_from) continue;          // (holds a pair of steps no alignment has)
         // (a slot of the in-flight set; the set is resolved when it is full)
 #pragma unroll
         for (int g = 0; g < T3_PEND; ++g)
@@ -5252,7 +5317,7 @@ struct gfal_scorer {
     bool child_index = false;
     uint32_t *d_inv_off = nullptr;
     uint4 *d_inv_ent = nullptr;
-    uint32_t *d_ct_key = nullptr, *d_ct_hash = nullptr, *d_ct_mult = nullptr;
+    uint32_t *d_ct_key = nullptr, *d_ct_hash = nullptr, *d_ct_mult = nullptr, *d_pair_bits = nullptr;
     uint32_t ct_mask = 0;
     int32_t *d_st_steps = nullptr, *d_st_len = nullptr;
     uint32_t *d_st_pass = nullptr, *d_st_g1 = nullptr;
@@ -5343,7 +5408,7 @@ void free_scorer(gfal_scorer *s)
                     s->d_worklist_sorted, s->d_wl_bins,
                     s->d_rows,       s->d_images,    s->d_path_off,   s->d_path_steps,
                     s->d_counts,     s->d_inv_off,   s->d_inv_ent,    s->d_ct_key,
-                    s->d_ct_hash,    s->d_ct_mult,   s->d_st_steps,   s->d_st_len,
+                    s->d_ct_hash,    s->d_ct_mult,   s->d_pair_bits, s->d_st_steps,   s->d_st_len,
                     s->d_st_pass,    s->d_st_g1,     s->d_child_in,   s->d_child_tmp,
                     s->d_st_bits,    s->d_st_bitsok, s->d_wl_pos,     s->d_wl_pos_sorted};
     for (void *b : bufs)
@@ -6368,7 +6433,7 @@ static int launch_scan3(gfal_scorer *s, hipStream_t st, const Items &items, cons
 
     TileArgs ta;
     ta.items = items;
-    ta.ct = ContentTable{s->d_ct_rec, s->ct_mask};
+    ta.ct = ContentTable{s->d_ct_rec, s->ct_mask, s->d_pair_bits};
     ta.images = s->d_images;
     ta.L = L;
     ta.lids = s->d_lids;
@@ -7044,7 +7109,9 @@ static int build_content_table(gfal_scorer *s)
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_ct_hash), (size_t)slots_pow2 * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_ct_mult), (size_t)slots_pow2 * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_ct_rec), (size_t)slots_pow2 * sizeof(uint4)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_pair_bits), ((size_t)1 << PAIR_BITS_LOG2) / 8));
     hipStream_t st = s->stream;
+    HIP_TRY(hipMemsetAsync(s->d_pair_bits, 0, ((size_t)1 << PAIR_BITS_LOG2) / 8, st));
     HIP_TRY(hipMemsetAsync(s->d_ct_key, 0xFF, (size_t)slots_pow2 * sizeof(uint32_t), st));
     HIP_TRY(hipMemsetAsync(s->d_ct_hash, 0, (size_t)slots_pow2 * sizeof(uint32_t), st));
     HIP_TRY(hipMemsetAsync(s->d_ct_mult, 0, (size_t)slots_pow2 * sizeof(uint32_t), st));
@@ -7055,7 +7122,7 @@ static int build_content_table(gfal_scorer *s)
         const unsigned blocks = (n_slots + 255u) / 256u;
         hipLaunchKernelGGL(k_ct_build, dim3(blocks), dim3(256), 0, st, items, s->d_slot_orig, n_slots,
                            s->d_item_hash, s->d_ct_key, s->d_ct_hash, s->d_ct_mult, s->ct_mask, s->d_ct_rec,
-                           s->d_rec3, s->d_item_r3);
+                           s->d_rec3, s->d_item_r3, s->d_pair_bits);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipStreamSynchronize(st));
