@@ -167,6 +167,41 @@ def test_siblings_and_prefixes_share_their_windows(gpu, monkeypatch):
     check_modes(monkeypatch, alns, paths, n_nodes)
 
 
+def test_substituted_steps_with_and_without_support(gpu, monkeypatch):
+    """k_tile's two shortcuts for positions with windows of their own.  The batch is 100
+    prefixes of one walk; the FIRST path of the second and third tile carries a substituted
+    step (the other paths' windows there are the reference's: copied, not looked up), other
+    paths carry their own.  Half of the substituted junctions also occur in alignments, on
+    either strand (the pair filter must let those windows through: they are contents), the
+    other half in none (skipped without a lookup)."""
+    rnd = random.Random(23)
+    V = 60
+    walk = [(rnd.randrange(V) << 1) | rnd.randrange(2) for _ in range(160)]
+    lens = sorted({rnd.randint(30, 160) for _ in range(400)}, reverse=True)[:100]
+    paths = [list(walk[:n]) for n in lens]
+    subs = {}                      # path index (by descending length: the scorer's order) -> position
+    for k in (31, 62, 5, 17, 40, 41, 70, 93):
+        q = rnd.randint(3, len(paths[k]) - 4)
+        paths[k][q] = ((V + k % 3) << 1) | rnd.randrange(2)      # a node the walk never visits
+        subs[k] = q
+    alns = []
+    for _ in range(3000):          # pieces of the walk, some reverse-complemented
+        m = rnd.randint(1, 12)
+        st = rnd.randrange(0, len(walk) - m)
+        b = list(walk[st:st + m])
+        alns.append([x ^ 1 for x in reversed(b)] if rnd.random() < 0.5 else b)
+    for k, q in subs.items():      # windows over half of the substituted steps, both strands
+        if k % 2:
+            continue
+        for _ in range(20):
+            lo = rnd.randint(max(0, q - 6), q)
+            hi = rnd.randint(q + 1, min(len(paths[k]), q + 7))
+            b = list(paths[k][lo:hi])
+            alns.append([x ^ 1 for x in reversed(b)] if rnd.random() < 0.5 else b)
+    rnd.shuffle(paths)
+    check_modes(monkeypatch, alns, paths, V + 4)
+
+
 def test_tiles_whose_paths_start_differently(gpu, monkeypatch):
     """The triage's shortcut (only alignments on the tile's first node can
     overhang) needs one first step per tile; tiles without one take the exact
