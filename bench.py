@@ -261,7 +261,7 @@ def spawn_ranks(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=600)      # (0.5 s of timed steps at 0.9 ms each)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="config3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
