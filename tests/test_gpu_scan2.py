@@ -106,6 +106,24 @@ def test_tile_boundaries(gpu, monkeypatch):
                     assert np.array_equal(g, e), (n, f, name)
 
 
+def test_list_arena_in_slabs(gpu, monkeypatch):
+    """GFAL_SCAN3_LIST_MB=1: the per-tile window lists do not fit the arena at once, so the
+    tiles go through k_tile_masks / k_tile / k_scan3 in slabs (one tile at a time here; the
+    reference array and the cold arguments come with the first slab only)."""
+    rnd = random.Random(29)
+    alns, paths = walk_case(rnd, 40, 150, 5000, 130, 10)
+    aoff, ast = csr(alns)
+    poff, pst = csr(paths)
+    monkeypatch.setenv("GFAL_SCAN", "3")
+    monkeypatch.setenv("GFAL_SCAN3_LIST_MB", "1")
+    with Scorer(aoff, ast, 48) as sc:
+        for f in (True, False):
+            got = sc.evaluate_paths(poff, pst, f)
+            exp = oracle.evaluate_paths(aoff, ast, poff, pst, f)
+            for name, g, e in zip(("bad", "good", "unaligned"), got, exp):
+                assert np.array_equal(g, e), (f, name, np.flatnonzero(g != e)[:8])
+
+
 def test_tiny_alphabet_overhangs(gpu, monkeypatch):
     """Two to three nodes: repeats everywhere, so the table holds few distinct
     windows with many duplicates, nearly every alignment touches the paths'
